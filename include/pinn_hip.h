@@ -1,0 +1,126 @@
+/*
+ * pinn_hip.h -- C ABI of libpinn_hip.so, the MI355X (gfx950) PINN training engine.
+ *
+ * The reference (pierremtb/PINNs-TF2.0) has no FFI/plugin boundary: its hot path is
+ * Python calling TensorFlow eager ops.  This ABI therefore sits *under* the reference's
+ * Python surface; each entry point below replaces the TensorFlow work done by the cited
+ * reference method, and `pinns-tf2.0_amd/utils/neuralnetwork.py` (same class/method
+ * names as the reference) is its only caller.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PINN_E* code on failure;
+ *     pinn_last_error() returns a thread-local message for the last failure.
+ *   - host pointers are borrowed for the duration of the call only; host interchange
+ *     dtype is always float64 (the reference's dtype, utils/neuralnetwork.py:24-26),
+ *     whatever the kernel compute dtype.
+ *   - the flat weight vector uses the reference layout (utils/neuralnetwork.py:68-89):
+ *     per Dense layer W.ravel() (row-major [fan_in, fan_out]) then b; the identification
+ *     problem appends lambda_1, lambda_2 (1d-burgers/ide_cont_burgers.py:98-107).
+ *   - a pinn_ctx is bound to one device and one stream and is not thread-safe.
+ *   - no torch / Python types anywhere in the signatures.
+ */
+#ifndef PINN_HIP_H
+#define PINN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pinn_ctx pinn_ctx;
+
+enum {
+  PINN_PDE_BURGERS = 0,     /* 1d-burgers/inf_cont_burgers.py:65-90   f = u_t + u u_x - nu u_xx            */
+  PINN_PDE_BURGERS_IDE = 1, /* 1d-burgers/ide_cont_burgers.py:56-85   f = u_t + l1 u u_x - exp(l2) u_xx    */
+  PINN_PDE_SCHRODINGER = 2  /* 1dcomplex-schrodinger/inf_cont_schrodinger.py:79-129                        */
+};
+enum { PINN_F32 = 0, PINN_F64 = 1 };
+enum {
+  PINN_OK = 0, PINN_EINVAL = -1, PINN_EHIP = -2, PINN_ESTATE = -3, PINN_ECOMM = -4,
+  PINN_EUNSUPPORTED = -5
+};
+
+/* diagnostics */
+const char* pinn_last_error(void);
+int pinn_abi_version(void);
+int pinn_device_count(int* n);
+/* name[0..cap) <- hipDeviceProp_t.gcnArchName etc. for Logger's banner (utils/logger.py:13-15) */
+int pinn_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
+
+/* NeuralNetwork.__init__ (utils/neuralnetwork.py:8-47): layers = hp["layers"], lb/ub = the
+ * Lambda normalisation bounds.  dtype = kernel arithmetic type. */
+int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* lb,
+                const double* ub, int pde_kind, int dtype, int device);
+int pinn_destroy(pinn_ctx* c);
+int pinn_num_params(pinn_ctx* c, int64_t* n);       /* incl. lambda_1, lambda_2 for IDE */
+
+/* Point sets.  *_total are the GLOBAL set sizes used as the mean() denominators, so that a
+ * rank holding a shard (n < n_total) produces partial sums that add up across ranks.
+ *   collocation: self.x_f, self.t_f      (inf_cont_burgers.py:55-56, inf_cont_schrodinger.py:56-57)
+ *   data:        fit(X_u, u) arguments   (utils/neuralnetwork.py:138-143); targets [n, n_out];
+ *                for PINN_PDE_BURGERS_IDE these points also carry the residual
+ *                (ide_cont_burgers.py:88-91) and no collocation set is used.
+ *   boundary:    X_lb, X_ub              (inf_cont_schrodinger.py:50-53), Schrodinger only. */
+int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_total);
+int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, int64_t n_total);
+int pinn_set_boundary(pinn_ctx* c, const double* X_lb, const double* X_ub, int64_t n,
+                      int64_t n_total);
+/* get_params (inf_cont_burgers.py:92): p[0] = nu for PINN_PDE_BURGERS */
+int pinn_set_pde_params(pinn_ctx* c, const double* p, int n);
+
+/* get_weights / set_weights (utils/neuralnetwork.py:68-89) */
+int pinn_set_weights(pinn_ctx* c, const double* w, int64_t n);
+int pinn_get_weights(pinn_ctx* c, double* w, int64_t n);
+
+/* NeuralNetwork.grad / get_loss_and_flat_grad (utils/neuralnetwork.py:55-59, 91-103) at the
+ * current weights: forward, residual, loss, flat gradient (+ all-reduce when a communicator is
+ * attached).  grad may be NULL.  terms (may be NULL) <- {mse_f, mse_data, mse_boundary}. */
+int pinn_loss_grad(pinn_ctx* c, double* loss, double* grad, double* terms);
+
+/* tf.keras.optimizers.Adam (utils/neuralnetwork.py:19-22) + tf_optimization loop (:105-116).
+ * pinn_adam_run does n_steps x {loss_grad; apply_gradients}; losses[i] (may be NULL) is the
+ * loss *before* update i, as tf_optimization_step returns it.  With losses == NULL the call
+ * returns without synchronising the stream. */
+int pinn_adam_init(pinn_ctx* c, double lr, double beta1, double beta2, double eps);
+int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses);
+
+/* custom_lbfgs.lbfgs (utils/custom_lbfgs.py:39-236) as driven by nt_optimization_steps
+ * (utils/neuralnetwork.py:131-136), device-resident.  pinn_lbfgs_begin does the initial
+ * evaluation (:65-76); pinn_lbfgs_run advances up to n_iters iterations.
+ *   iters[i], losses[i]: the (nIter, f) pairs custom_lbfgs would have passed to log_fn (:217-218)
+ *   n_logged: how many pairs were written;  done: 0 running, 1 maxIter reached, >1 break reason
+ * The last-iteration quirk is reproduced: the model weights end at the last *evaluated* x. */
+int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double tol_fun,
+                     double tol_x, double max_eval);
+int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged,
+                   int* done);
+/* x as custom_lbfgs returns it (:236) -- one step past the model weights */
+int pinn_lbfgs_get_x(pinn_ctx* c, double* x, int64_t n);
+
+/* self.model(X_star) (utils/neuralnetwork.py:151-153): out[N, n_out] */
+int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out);
+/* f_model() at the stored collocation points (inf_cont_burgers.py:65-90): f[n_f, n_out]
+ * (IDE: at the data points) */
+int pinn_residual(pinn_ctx* c, double* f, int64_t n);
+
+/* Data-parallel: one process per GPU, RCCL all-reduce(SUM) of [grad | loss terms].
+ * Rank 0 calls pinn_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * out-of-band channel; every rank then calls pinn_comm_init. */
+int pinn_comm_unique_id(char* id128);
+int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank);
+
+/* Measurement: bracket every launch of the dominant kernel (the loss+grad kernels) with
+ * hipEvents on the engine's stream.  pinn_timing_read drains them: avg_ms[0] forward sweep,
+ * avg_ms[1] reverse sweep, avg_ms[2] whole evaluation; n = evaluations timed. */
+int pinn_timing_enable(pinn_ctx* c, int max_evals);
+int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);
+int pinn_sync(pinn_ctx* c);
+/* which kernel family serves the loss+grad evaluation: 0 generic, 1 fused width-20 */
+int pinn_set_kernel_path(pinn_ctx* c, int path);
+int pinn_get_kernel_path(pinn_ctx* c, int* path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_HIP_H */

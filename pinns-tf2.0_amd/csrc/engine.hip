@@ -1,0 +1,709 @@
+// engine.hip -- context, device memory, launch sequencing and the C ABI (include/pinn_hip.h)
+// of the MI355X PINN engine.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip -o libpinn_hip.so -lrccl
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pinn_hip.h"
+#include "kernels_fused20.h"
+#include "kernels_generic.h"
+#include "kernels_optim.h"
+
+using namespace pinn;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(PINN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define NCCLCHK(expr)                                                                     \
+  do {                                                                                    \
+    ncclResult_t r_ = (expr);                                                             \
+    if (r_ != ncclSuccess)                                                                \
+      return fail(PINN_ECOMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r_),     \
+                  __FILE__, __LINE__);                                                    \
+  } while (0)
+
+#define REQUIRE(cond, ...)                                \
+  do {                                                    \
+    if (!(cond)) return fail(PINN_EINVAL, __VA_ARGS__);   \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+static constexpr int CHUNK_POINTS = 32768;   // points per forward/backward launch pair
+static constexpr int LOSS_SLOTS = 4;         // residual, data, boundary, pad
+
+struct pinn_ctx {
+  int device = 0, dtype = PINN_F32, pde = PINN_PDE_BURGERS, path = 0;
+  hipStream_t stream = nullptr;
+  NetDesc nd{};
+  int layers[MAX_DENSE + 1]{};
+  int n_layers = 0;
+  double lb[2]{}, ub[2]{}, nu = 0.0;
+
+  // host copies of the point sets (float64, as handed over)
+  std::vector<double> Xf, Xu, U, Xlo, Xhi;
+  int64_t nf_total = 0, nu_total = 0, nb_total = 0;
+  bool sets_dirty = true;
+  SetDesc sd{};
+
+  // device: training set (compute dtype)
+  void *xs = nullptr, *ts = nullptr, *tgt = nullptr;
+  // device: parameters / optimiser (float64) + compute-dtype mirror
+  double *theta = nullptr, *gl = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  void* theta_r = nullptr;
+  // device: scratch
+  void *S = nullptr, *O = nullptr, *ZA = nullptr, *ZB = nullptr, *part = nullptr;
+  size_t cap_S = 0, cap_O = 0, cap_Z = 0, cap_part = 0, cap_pts = 0;
+  int chunk = 0, n_rows = 0, R = 0;
+  // device: evaluation-only scratch (predict)
+  void *xe = nullptr, *te = nullptr, *Oe = nullptr;
+  size_t cap_eval = 0;
+  double* f_out = nullptr;
+  size_t cap_f = 0;
+
+  // Adam
+  double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-7;
+  int64_t adam_t = 0;
+  bool adam_ready = false;
+  double* loss_hist = nullptr;
+  size_t cap_loss_hist = 0;
+
+  // L-BFGS
+  LbfgsState* lb_state = nullptr;
+  double *lb_x = nullptr, *lb_d = nullptr, *lb_gold = nullptr, *lb_S = nullptr, *lb_Y = nullptr,
+         *lb_ro = nullptr, *lb_al = nullptr, *lb_q = nullptr, *lb_log_loss = nullptr;
+  int* lb_log_iter = nullptr;
+  int lb_max_iter = 0, lb_ncorr = 0, lb_cap_corr = 0, lb_cap_log = 0, lb_logged_read = 0;
+  double lb_lr = 1.0, lb_tol_fun = 0, lb_tol_x = 0, lb_max_eval = 0;
+  int lb_iters_issued = 0;
+  bool lb_ready = false;
+
+  // RCCL
+  ncclComm_t comm = nullptr;
+  int n_ranks = 1, rank = 0;
+
+  // timing
+  std::vector<hipEvent_t> ev;
+  int ev_used = 0, ev_cap_evals = 0;
+  bool timing = false;
+};
+
+static size_t real_size(const pinn_ctx* c) { return c->dtype == PINN_F64 ? 8 : 4; }
+
+template <typename T>
+static int dev_alloc(T** p, size_t bytes) {
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  HIPCHK(hipMalloc((void**)p, bytes ? bytes : 16));
+  return 0;
+}
+
+static int upload_real(pinn_ctx* c, void* dst, const double* src, size_t n) {
+  if (c->dtype == PINN_F64) {
+    HIPCHK(hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  } else {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+    HIPCHK(hipMemcpyAsync(dst, tmp.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// training-set assembly: [boundary-lo | boundary-hi | data | collocation | pad]
+// ------------------------------------------------------------------------------------------
+static int ensure_sets(pinn_ctx* c) {
+  if (!c->sets_dirty) return 0;
+  const int n_b = (int)(c->Xlo.size() / 2), n_u = (int)(c->Xu.size() / 2),
+            n_f = (int)(c->Xf.size() / 2);
+  const int NO = c->nd.n_out;
+  if (c->pde == PINN_PDE_BURGERS_IDE)
+    REQUIRE(n_f == 0, "identification evaluates the residual at the data points; no collocation set");
+  if (c->pde != PINN_PDE_SCHRODINGER) REQUIRE(n_b == 0, "boundary pairs are Schrodinger-only");
+  const int n_all = 2 * n_b + n_u + n_f;
+  REQUIRE(n_all > 0, "no training points set");
+  const int n_pad = (n_all + 63) / 64 * 64;
+  REQUIRE(2 * n_b <= CHUNK_POINTS / 2, "too many boundary pairs for one chunk (%d)", n_b);
+  SetDesc sd{};
+  sd.n_b = n_b; sd.n_u = n_u; sd.n_f = n_f; sd.n_all = n_all; sd.n_pad = n_pad;
+  sd.inv_nb = c->nb_total > 0 ? 1.0 / (double)c->nb_total : 0.0;
+  sd.inv_nu = c->nu_total > 0 ? 1.0 / (double)c->nu_total : 0.0;
+  sd.inv_nf = c->nf_total > 0 ? 1.0 / (double)c->nf_total : 0.0;
+  c->sd = sd;
+
+  std::vector<double> hx(n_pad), ht(n_pad), htg((size_t)NO * n_pad, 0.0);
+  int g = 0;
+  for (int i = 0; i < n_b; ++i, ++g) { hx[g] = c->Xlo[2 * i]; ht[g] = c->Xlo[2 * i + 1]; }
+  for (int i = 0; i < n_b; ++i, ++g) { hx[g] = c->Xhi[2 * i]; ht[g] = c->Xhi[2 * i + 1]; }
+  for (int i = 0; i < n_u; ++i, ++g) {
+    hx[g] = c->Xu[2 * i]; ht[g] = c->Xu[2 * i + 1];
+    for (int o = 0; o < NO; ++o) htg[(size_t)o * n_pad + g] = c->U[(size_t)i * NO + o];
+  }
+  for (int i = 0; i < n_f; ++i, ++g) { hx[g] = c->Xf[2 * i]; ht[g] = c->Xf[2 * i + 1]; }
+  for (; g < n_pad; ++g) { hx[g] = c->lb[0]; ht[g] = c->lb[1]; }   // inert padding (zero seeds)
+
+  const size_t rs = real_size(c);
+  if ((size_t)n_pad > c->cap_pts) {
+    if (dev_alloc(&c->xs, n_pad * rs)) return PINN_EHIP;
+    if (dev_alloc(&c->ts, n_pad * rs)) return PINN_EHIP;
+    if (dev_alloc(&c->tgt, (size_t)NO * n_pad * rs)) return PINN_EHIP;
+    if (dev_alloc(&c->O, (size_t)NO * n_pad * 4 * rs)) return PINN_EHIP;
+    c->cap_pts = n_pad;
+  }
+  if (upload_real(c, c->xs, hx.data(), n_pad)) return PINN_EHIP;
+  if (upload_real(c, c->ts, ht.data(), n_pad)) return PINN_EHIP;
+  if (upload_real(c, c->tgt, htg.data(), (size_t)NO * n_pad)) return PINN_EHIP;
+
+  c->chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
+  c->n_rows = c->chunk / 64;
+  const size_t W = c->nd.width, H = c->nd.n_hidden;
+  const size_t need_S = H * W * (size_t)c->chunk * 4 * rs, need_Z = W * (size_t)c->chunk * 4 * rs;
+  const size_t need_part = (size_t)c->n_rows * c->R * rs;
+  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
+  if (need_Z > c->cap_Z) {
+    if (dev_alloc(&c->ZA, need_Z)) return PINN_EHIP;
+    if (dev_alloc(&c->ZB, need_Z)) return PINN_EHIP;
+    c->cap_Z = need_Z;
+  }
+  if (need_part > c->cap_part) { if (dev_alloc(&c->part, need_part)) return PINN_EHIP; c->cap_part = need_part; }
+  c->sets_dirty = false;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// one loss+gradient evaluation at the current weights -> c->gl  (no host sync)
+// ------------------------------------------------------------------------------------------
+template <typename real, int PDE>
+static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4) {
+  constexpr int JT = sizeof(real) == 4 ? 20 : 10;
+  constexpr int KT = sizeof(real) == 4 ? 10 : 5;
+  const SetDesc sd = c->sd;
+  const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
+  const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
+  if (ev4) HIPCHK(hipEventRecord(ev4[0], c->stream));
+  if (c->path == 1) {
+    const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
+                                             (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
+                                             st, (real)c->nu, (real*)c->part, c->R, c->stream);
+    if (rc) return fail(PINN_EHIP, "fused20 launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
+  } else {
+    for (int base = 0, ci = 0; base < sd.n_pad; base += c->chunk, ++ci) {
+      const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
+      const dim3 grid(pts / 64), block(64);
+      hipLaunchKernelGGL((k_forward<real, JT>), grid, block, 0, c->stream, c->nd,
+                         (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, base,
+                         sd.n_pad, c->chunk, lbx, lbt, sx, st, (vec4<real>*)c->S,
+                         (vec4<real>*)c->O);
+      if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
+      hipLaunchKernelGGL((k_backward<real, PDE, KT>), grid, block, 0, c->stream, c->nd, sd,
+                         (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts,
+                         (const real*)c->tgt, base, sd.n_pad, c->chunk, lbx, lbt, sx, st,
+                         (real)c->nu, (const vec4<real>*)c->S, (const vec4<real>*)c->O,
+                         (vec4<real>*)c->ZA, (vec4<real>*)c->ZB, (real*)c->part, c->R,
+                         ci > 0 ? 1 : 0);
+    }
+  }
+  if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
+  hipLaunchKernelGGL((k_reduce_rows<real>), dim3((c->R + 255) / 256), dim3(256), 0, c->stream,
+                     (const real*)c->part, c->path == 1 ? fused20_rows(sd) : c->n_rows, c->R, c->gl);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int eval_loss_grad(pinn_ctx* c) {
+  int rc = ensure_sets(c);
+  if (rc) return rc;
+  hipEvent_t* ev4 = nullptr;
+  if (c->timing && c->ev_used < c->ev_cap_evals) ev4 = &c->ev[(size_t)4 * c->ev_used];
+#define DISPATCH(REAL)                                                       \
+  switch (c->pde) {                                                          \
+    case PINN_PDE_BURGERS: rc = launch_sweeps<REAL, 0>(c, ev4); break;       \
+    case PINN_PDE_BURGERS_IDE: rc = launch_sweeps<REAL, 1>(c, ev4); break;   \
+    default: rc = launch_sweeps<REAL, 2>(c, ev4); break;                     \
+  }
+  if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
+#undef DISPATCH
+  if (rc) return rc;
+  if (c->comm) NCCLCHK(ncclAllReduce(c->gl, c->gl, (size_t)c->R, ncclDouble, ncclSum, c->comm, c->stream));
+  if (ev4) { HIPCHK(hipEventRecord(ev4[3], c->stream)); c->ev_used++; }
+  return 0;
+}
+
+static int cast_weights(pinn_ctx* c) {
+  const int n = c->nd.n_theta;
+  if (c->dtype == PINN_F64)
+    hipLaunchKernelGGL((k_cast_weights<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (double*)c->theta_r);
+  else
+    hipLaunchKernelGGL((k_cast_weights<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (float*)c->theta_r);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* pinn_last_error(void) { return g_err.c_str(); }
+int pinn_abi_version(void) { return 1; }
+
+int pinn_device_count(int* n) {
+  REQUIRE(n, "null");
+  HIPCHK(hipGetDeviceCount(n));
+  return 0;
+}
+
+int pinn_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes) {
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, device));
+  if (name && cap > 0) snprintf(name, cap, "%s (%s)", p.name, p.gcnArchName);
+  if (n_cu) *n_cu = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return 0;
+}
+
+int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* lb,
+                const double* ub, int pde_kind, int dtype, int device) {
+  REQUIRE(out && layers && lb && ub, "null argument");
+  REQUIRE(n_layers >= 3 && n_layers <= MAX_DENSE + 1, "need 3..%d layer sizes, got %d", MAX_DENSE + 1, n_layers);
+  REQUIRE(layers[0] == 2, "input dimension must be 2 (x, t), got %d", layers[0]);
+  REQUIRE(dtype == PINN_F32 || dtype == PINN_F64, "dtype must be PINN_F32 or PINN_F64");
+  REQUIRE(pde_kind >= 0 && pde_kind <= 2, "unknown pde kind %d", pde_kind);
+  const int W = layers[1], NO = layers[n_layers - 1];
+  for (int i = 1; i < n_layers - 1; ++i)
+    REQUIRE(layers[i] == W, "all hidden widths must be equal (the reference's sizes_w assumes it, "
+                            "utils/neuralnetwork.py:40-45); got %d vs %d", layers[i], W);
+  REQUIRE(W >= 1 && W <= MAX_WIDTH, "hidden width %d outside 1..%d", W, MAX_WIDTH);
+  REQUIRE(NO == (pde_kind == PINN_PDE_SCHRODINGER ? 2 : 1), "output size %d does not match the PDE kind", NO);
+  REQUIRE(ub[0] > lb[0] && ub[1] > lb[1], "ub must exceed lb");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  REQUIRE(device >= 0 && device < ndev, "device %d not present (%d devices)", device, ndev);
+  HIPCHK(hipSetDevice(device));
+
+  pinn_ctx* c = new pinn_ctx();
+  c->device = device; c->dtype = dtype; c->pde = pde_kind; c->n_layers = n_layers;
+  for (int i = 0; i < n_layers; ++i) c->layers[i] = layers[i];
+  c->lb[0] = lb[0]; c->lb[1] = lb[1]; c->ub[0] = ub[0]; c->ub[1] = ub[1];
+  c->nu = 0.01 / M_PI;
+  NetDesc& nd = c->nd;
+  nd.n_hidden = n_layers - 2; nd.width = W; nd.n_out = NO;
+  int off = 0;
+  for (int d = 0; d < n_layers - 1; ++d) {
+    nd.off_w[d] = off; off += layers[d] * layers[d + 1];
+    nd.off_b[d] = off; off += layers[d + 1];
+  }
+  nd.n_net = off;
+  nd.n_theta = off + (pde_kind == PINN_PDE_BURGERS_IDE ? 2 : 0);
+  c->R = nd.n_theta + LOSS_SLOTS;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(PINN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  const size_t n = nd.n_theta;
+  if (dev_alloc(&c->theta, n * 8) || dev_alloc(&c->gl, (size_t)c->R * 8) ||
+      dev_alloc(&c->adam_m, n * 8) || dev_alloc(&c->adam_v, n * 8) ||
+      dev_alloc(&c->theta_r, n * real_size(c))) { delete c; return PINN_EHIP; }
+  HIPCHK(hipMemsetAsync(c->theta, 0, n * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->theta_r, 0, n * real_size(c), c->stream));
+  HIPCHK(hipMemsetAsync(c->gl, 0, (size_t)c->R * 8, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  // width-20 Burgers nets take the fused path by default
+  c->path = (fused20_supported(nd) && pde_kind != PINN_PDE_SCHRODINGER) ? 1 : 0;
+  *out = c;
+  return 0;
+}
+
+int pinn_destroy(pinn_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  void* ptrs[] = {c->xs, c->ts, c->tgt, c->theta, c->gl, c->adam_m, c->adam_v, c->theta_r, c->S,
+                  c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
+                  c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
+                  c->lb_q, c->lb_log_loss, c->lb_log_iter};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int pinn_num_params(pinn_ctx* c, int64_t* n) {
+  REQUIRE(c && n, "null");
+  *n = c->nd.n_theta;
+  return 0;
+}
+
+int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_total) {
+  REQUIRE(c && (X_f || n == 0) && n >= 0 && n_total >= n, "bad collocation arguments");
+  c->Xf.assign(X_f, X_f + 2 * n);
+  c->nf_total = n_total;
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, int64_t n_total) {
+  REQUIRE(c && ((X_u && u) || n == 0) && n >= 0 && n_total >= n, "bad data arguments");
+  c->Xu.assign(X_u, X_u + 2 * n);
+  c->U.assign(u, u + (size_t)c->nd.n_out * n);
+  c->nu_total = n_total;
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_set_boundary(pinn_ctx* c, const double* X_lb, const double* X_ub, int64_t n, int64_t n_total) {
+  REQUIRE(c && ((X_lb && X_ub) || n == 0) && n >= 0 && n_total >= n, "bad boundary arguments");
+  REQUIRE(c->pde == PINN_PDE_SCHRODINGER || n == 0, "boundary pairs are Schrodinger-only");
+  c->Xlo.assign(X_lb, X_lb + 2 * n);
+  c->Xhi.assign(X_ub, X_ub + 2 * n);
+  c->nb_total = n_total;
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_set_pde_params(pinn_ctx* c, const double* p, int n) {
+  REQUIRE(c && p && n >= 1, "bad pde params");
+  c->nu = p[0];
+  return 0;
+}
+
+int pinn_set_weights(pinn_ctx* c, const double* w, int64_t n) {
+  REQUIRE(c && w, "null");
+  REQUIRE(n == c->nd.n_theta, "weight vector has %lld entries, expected %d", (long long)n, c->nd.n_theta);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->theta, w, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+  int rc = cast_weights(c);
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pinn_get_weights(pinn_ctx* c, double* w, int64_t n) {
+  REQUIRE(c && w, "null");
+  REQUIRE(n == c->nd.n_theta, "weight vector has %lld entries, expected %d", (long long)n, c->nd.n_theta);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(w, c->theta, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pinn_loss_grad(pinn_ctx* c, double* loss, double* grad, double* terms) {
+  REQUIRE(c, "null");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = eval_loss_grad(c);
+  if (rc) return rc;
+  std::vector<double> h(c->R);
+  HIPCHK(hipMemcpyAsync(h.data(), c->gl, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int P = c->nd.n_theta;
+  if (loss) *loss = h[P] + h[P + 1] + h[P + 2];
+  if (terms) { terms[0] = h[P]; terms[1] = h[P + 1]; terms[2] = h[P + 2]; }
+  if (grad) memcpy(grad, h.data(), (size_t)P * 8);
+  return 0;
+}
+
+int pinn_adam_init(pinn_ctx* c, double lr, double beta1, double beta2, double eps) {
+  REQUIRE(c, "null");
+  REQUIRE(lr > 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "bad Adam hyper-parameters");
+  HIPCHK(hipSetDevice(c->device));
+  c->lr = lr; c->b1 = beta1; c->b2 = beta2; c->eps = eps; c->adam_t = 0;
+  HIPCHK(hipMemsetAsync(c->adam_m, 0, (size_t)c->nd.n_theta * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->adam_v, 0, (size_t)c->nd.n_theta * 8, c->stream));
+  c->adam_ready = true;
+  return 0;
+}
+
+int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
+  REQUIRE(c && n_steps >= 0, "bad arguments");
+  REQUIRE(c->adam_ready, "pinn_adam_init has not been called");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_steps == 0) return 0;
+  if (losses && (size_t)n_steps > c->cap_loss_hist) {
+    if (dev_alloc(&c->loss_hist, (size_t)n_steps * 8)) return PINN_EHIP;
+    c->cap_loss_hist = n_steps;
+  }
+  const int n = c->nd.n_theta;
+  for (int s = 0; s < n_steps; ++s) {
+    int rc = eval_loss_grad(c);
+    if (rc) return rc;
+    c->adam_t += 1;
+    const double t = (double)c->adam_t;
+    const double alpha = c->lr * std::sqrt(1.0 - std::pow(c->b2, t)) / (1.0 - std::pow(c->b1, t));
+    double* slot = losses ? c->loss_hist + s : nullptr;
+    if (c->dtype == PINN_F64)
+      hipLaunchKernelGGL((k_adam<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (double*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n);
+    else
+      hipLaunchKernelGGL((k_adam<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (float*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n);
+  }
+  HIPCHK(hipGetLastError());
+  if (losses) {
+    HIPCHK(hipMemcpyAsync(losses, c->loss_hist, (size_t)n_steps * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double tol_fun,
+                     double tol_x, double max_eval) {
+  REQUIRE(c && max_iter >= 0 && n_corr >= 1 && lr > 0, "bad L-BFGS arguments");
+  HIPCHK(hipSetDevice(c->device));
+  const size_t n = c->nd.n_theta;
+  c->lb_max_iter = max_iter; c->lb_lr = lr; c->lb_ncorr = n_corr;
+  c->lb_tol_fun = tol_fun; c->lb_tol_x = tol_x;
+  c->lb_max_eval = max_eval > 0 ? max_eval : 1.25 * max_iter;     // custom_lbfgs.py:50
+  c->lb_iters_issued = 0; c->lb_logged_read = 0;
+  c->lb_ready = false;
+  if (max_iter == 0) { c->lb_ready = true; return 0; }           // custom_lbfgs.py:43-44
+  if (!c->lb_state) {
+    if (dev_alloc(&c->lb_state, sizeof(LbfgsState)) || dev_alloc(&c->lb_x, n * 8) ||
+        dev_alloc(&c->lb_d, n * 8) || dev_alloc(&c->lb_gold, n * 8) || dev_alloc(&c->lb_q, n * 8))
+      return PINN_EHIP;
+  }
+  if (n_corr > c->lb_cap_corr) {
+    if (dev_alloc(&c->lb_S, (size_t)n_corr * n * 8) || dev_alloc(&c->lb_Y, (size_t)n_corr * n * 8) ||
+        dev_alloc(&c->lb_ro, (size_t)n_corr * 8) || dev_alloc(&c->lb_al, (size_t)n_corr * 8))
+      return PINN_EHIP;
+    c->lb_cap_corr = n_corr;
+  }
+  if (max_iter + 1 > c->lb_cap_log) {
+    if (dev_alloc(&c->lb_log_loss, (size_t)(max_iter + 1) * 8) ||
+        dev_alloc(&c->lb_log_iter, (size_t)(max_iter + 1) * 4))
+      return PINN_EHIP;
+    c->lb_cap_log = max_iter + 1;
+  }
+  LbfgsState z{};
+  z.Hdiag = 1.0;
+  HIPCHK(hipMemcpyAsync(c->lb_state, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->lb_x, c->theta, n * 8, hipMemcpyDeviceToDevice, c->stream));
+  int rc = eval_loss_grad(c);                                      // :65
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, (int)n, (int)n,
+                     max_iter, c->lb_max_eval, tol_fun, tol_x, c->lb_state, c->gl, c->lb_d,
+                     c->lb_log_iter, c->lb_log_loss, 1);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->lb_ready = true;
+  return 0;
+}
+
+int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged, int* done) {
+  REQUIRE(c && n_iters >= 0, "bad arguments");
+  REQUIRE(c->lb_ready, "pinn_lbfgs_begin has not been called");
+  HIPCHK(hipSetDevice(c->device));
+  if (n_logged) *n_logged = 0;
+  if (c->lb_max_iter == 0) { if (done) *done = 1; return 0; }
+  const int n = c->nd.n_theta;
+  for (int s = 0; s < n_iters && c->lb_iters_issued < c->lb_max_iter; ++s) {
+    c->lb_iters_issued += 1;
+    if (c->dtype == PINN_F64)
+      hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
+    else
+      hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
+    if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
+    int rc = eval_loss_grad(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
+                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state, c->gl, c->lb_d,
+                       c->lb_log_iter, c->lb_log_loss, 0);
+  }
+  HIPCHK(hipGetLastError());
+  LbfgsState hs;
+  HIPCHK(hipMemcpyAsync(&hs, c->lb_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const int fresh = hs.n_logged - c->lb_logged_read;
+  if (fresh > 0 && iters && losses) {
+    HIPCHK(hipMemcpy(iters, c->lb_log_iter + c->lb_logged_read, (size_t)fresh * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(losses, c->lb_log_loss + c->lb_logged_read, (size_t)fresh * 8, hipMemcpyDeviceToHost));
+  }
+  c->lb_logged_read = hs.n_logged;
+  if (n_logged) *n_logged = fresh > 0 ? fresh : 0;
+  if (done) *done = hs.done;
+  return 0;
+}
+
+int pinn_lbfgs_get_x(pinn_ctx* c, double* x, int64_t n) {
+  REQUIRE(c && x && n == c->nd.n_theta, "bad arguments");
+  REQUIRE(c->lb_x, "no L-BFGS run yet");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(x, c->lb_x, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
+  REQUIRE(c && X && out && n >= 0, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  if (n == 0) return 0;
+  const size_t rs = real_size(c);
+  const int NO = c->nd.n_out;
+  const size_t W = c->nd.width, H = c->nd.n_hidden;
+  const int n_pad = (int)((n + 63) / 64 * 64);
+  const int chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
+  if ((size_t)n_pad > c->cap_eval) {
+    if (dev_alloc(&c->xe, n_pad * rs) || dev_alloc(&c->te, n_pad * rs) ||
+        dev_alloc(&c->Oe, (size_t)NO * n_pad * 4 * rs)) return PINN_EHIP;
+    c->cap_eval = n_pad;
+  }
+  const size_t need_S = H * W * (size_t)chunk * 4 * rs;
+  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
+  std::vector<double> hx(n_pad, c->lb[0]), ht(n_pad, c->lb[1]);
+  for (int64_t i = 0; i < n; ++i) { hx[i] = X[2 * i]; ht[i] = X[2 * i + 1]; }
+  if (upload_real(c, c->xe, hx.data(), n_pad) || upload_real(c, c->te, ht.data(), n_pad)) return PINN_EHIP;
+  const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
+  for (int base = 0; base < n_pad; base += chunk) {
+    const int pts = (n_pad - base < chunk) ? n_pad - base : chunk;
+    if (c->dtype == PINN_F64)
+      hipLaunchKernelGGL((k_forward<double, 10>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const double*)c->theta_r, (const double*)c->xe, (const double*)c->te, base, n_pad, chunk, c->lb[0], c->lb[1], sx, st, (vec4<double>*)c->S, (vec4<double>*)c->Oe);
+    else
+      hipLaunchKernelGGL((k_forward<float, 20>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const float*)c->theta_r, (const float*)c->xe, (const float*)c->te, base, n_pad, chunk, (float)c->lb[0], (float)c->lb[1], (float)sx, (float)st, (vec4<float>*)c->S, (vec4<float>*)c->Oe);
+  }
+  HIPCHK(hipGetLastError());
+  std::vector<char> ho((size_t)NO * n_pad * 4 * rs);
+  HIPCHK(hipMemcpyAsync(ho.data(), c->Oe, ho.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int o = 0; o < NO; ++o)
+    for (int64_t i = 0; i < n; ++i) {
+      const size_t idx = ((size_t)o * n_pad + i) * 4;   // .x of vec4
+      out[(size_t)i * NO + o] = c->dtype == PINN_F64 ? ((const double*)ho.data())[idx]
+                                                     : (double)((const float*)ho.data())[idx];
+    }
+  return 0;
+}
+
+int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
+  REQUIRE(c && f, "null");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_sets(c);
+  if (rc) return rc;
+  const SetDesc sd = c->sd;
+  const bool ide = c->pde == PINN_PDE_BURGERS_IDE;
+  const int first = ide ? 2 * sd.n_b : 2 * sd.n_b + sd.n_u;
+  const int cnt = ide ? sd.n_u : sd.n_f;
+  REQUIRE(n == cnt, "residual buffer holds %lld points, the set has %d", (long long)n, cnt);
+  if (cnt == 0) return 0;
+  const int NO = c->nd.n_out;
+  if ((size_t)cnt * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)cnt * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)cnt * NO; }
+  const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
+  for (int base = 0; base < sd.n_pad; base += c->chunk) {
+    const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
+    if (c->dtype == PINN_F64)
+      hipLaunchKernelGGL((k_forward<double, 10>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, base, sd.n_pad, c->chunk, c->lb[0], c->lb[1], sx, st, (vec4<double>*)c->S, (vec4<double>*)c->O);
+    else
+      hipLaunchKernelGGL((k_forward<float, 20>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const float*)c->theta_r, (const float*)c->xs, (const float*)c->ts, base, sd.n_pad, c->chunk, (float)c->lb[0], (float)c->lb[1], (float)sx, (float)st, (vec4<float>*)c->S, (vec4<float>*)c->O);
+  }
+  const dim3 grid((cnt + 255) / 256), block(256);
+#define RES(REAL, P) hipLaunchKernelGGL((k_residual<REAL, P>), grid, block, 0, c->stream, first, cnt, sd.n_pad, (const vec4<REAL>*)c->O, (const REAL*)c->theta_r, c->nd.n_net, (REAL)c->nu, c->f_out, NO)
+  if (c->dtype == PINN_F64) { if (c->pde == 0) RES(double, 0); else if (c->pde == 1) RES(double, 1); else RES(double, 2); }
+  else { if (c->pde == 0) RES(float, 0); else if (c->pde == 1) RES(float, 1); else RES(float, 2); }
+#undef RES
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(f, c->f_out, (size_t)cnt * NO * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pinn_comm_unique_id(char* id128) {
+  REQUIRE(id128, "null");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return 0;
+}
+
+int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank) {
+  REQUIRE(c && id128 && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad communicator arguments");
+  HIPCHK(hipSetDevice(c->device));
+  if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  NCCLCHK(ncclCommInitRank(&c->comm, n_ranks, id, rank));
+  c->n_ranks = n_ranks; c->rank = rank;
+  return 0;
+}
+
+int pinn_timing_enable(pinn_ctx* c, int max_evals) {
+  REQUIRE(c && max_evals >= 0, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  while ((int)c->ev.size() < 4 * max_evals) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    c->ev.push_back(e);
+  }
+  c->ev_cap_evals = max_evals; c->ev_used = 0; c->timing = max_evals > 0;
+  return 0;
+}
+
+int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n) {
+  REQUIRE(c && avg_ms && n, "null");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double a = 0, b = 0, t = 0;
+  for (int i = 0; i < c->ev_used; ++i) {
+    float m01 = 0, m02 = 0, m03 = 0;
+    HIPCHK(hipEventElapsedTime(&m01, c->ev[4 * i], c->ev[4 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&m02, c->ev[4 * i], c->ev[4 * i + 2]));
+    HIPCHK(hipEventElapsedTime(&m03, c->ev[4 * i], c->ev[4 * i + 3]));
+    a += m01; b += m02; t += m03;
+  }
+  *n = c->ev_used;
+  const double k = c->ev_used ? 1.0 / c->ev_used : 0.0;
+  avg_ms[0] = a * k; avg_ms[1] = b * k; avg_ms[2] = t * k;
+  c->ev_used = 0;
+  return 0;
+}
+
+int pinn_sync(pinn_ctx* c) {
+  REQUIRE(c, "null");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pinn_set_kernel_path(pinn_ctx* c, int path) {
+  REQUIRE(c && (path == 0 || path == 1), "path must be 0 (generic) or 1 (fused width-20)");
+  if (path == 1)
+    REQUIRE(fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER,
+            "the fused path needs hidden width 20 and a Burgers problem");
+  c->path = path;
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_get_kernel_path(pinn_ctx* c, int* path) {
+  REQUIRE(c && path, "null");
+  *path = c->path;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// kernels_generic.h -- shape-generic loss+gradient kernels (any uniform hidden width <= 128,
+// 1 or 2 outputs, all three PDE kinds).  One lane = one point; weights are wave-uniform and
+// are fetched through the scalar cache (s_load) so every FMA is VGPR x SGPR; the per-layer
+// Taylor channels (a, z_x, z_t, z_xx) are stashed in an HBM/L2-resident scratch laid out
+// [layer][feature][point] so that a wave's access is one contiguous 1 KiB (f32) line.
+//
+// Math: SURVEY.md Appendix A (4-channel forward A.1, seeds A.2, reverse sweep A.3), which
+// is what the reference's nested GradientTapes compute
+// (1d-burgers/inf_cont_burgers.py:65-90, utils/neuralnetwork.py:55-59).
+#pragma once
+#include "wave.h"
+
+namespace pinn {
+
+constexpr int MAX_DENSE = 16;   // dense layers incl. the linear output layer
+constexpr int MAX_WIDTH = 128;
+
+struct NetDesc {
+  int n_hidden;              // H tanh layers, all of width W
+  int width;                 // W
+  int n_out;                 // 1 (Burgers) or 2 (Schrodinger)
+  int off_w[MAX_DENSE];      // offsets into the flat weight vector (reference layout)
+  int off_b[MAX_DENSE];
+  int n_net;                 // number of network scalars (without lambdas)
+  int n_theta;               // n_net (+2 for identification)
+};
+
+// Training-set geometry for one evaluation.  Points are stored in class order
+// [boundary-lo | boundary-hi | data | collocation | pad].
+struct SetDesc {
+  int n_b, n_u, n_f;         // local counts
+  int n_all;                 // 2*n_b + n_u + n_f
+  int n_pad;                 // rounded up to a multiple of 64
+  double inv_nb, inv_nu, inv_nf;   // 1 / GLOBAL set sizes (mean() denominators)
+};
+
+template <typename real> __device__ __forceinline__ real tanh_r(real z);
+template <> __device__ __forceinline__ float tanh_r<float>(float z) { return tanhf(z); }
+template <> __device__ __forceinline__ double tanh_r<double>(double z) { return tanh(z); }
+
+// ---------------------------------------------------------------------------------------------
+// Forward sweep: Taylor channels through every layer for points [base, base+gridDim*64).
+//   S[(d*W + k)*n_pad + pt] = (a, zp, zq, zr) of dense layer d, feature k      (d < H)
+//   O[o*n_pad + pt]         = (u_o, d/dx, d/dt, d2/dx2) of output o
+// ---------------------------------------------------------------------------------------------
+template <typename real, int JT>
+__global__ __launch_bounds__(64) void k_forward(NetDesc nd, const real* __restrict__ th,
+                                                const real* __restrict__ xs,
+                                                const real* __restrict__ ts, int base, int n_pad,
+                                                int s_pad, real lbx, real lbt, real sx, real st,
+                                                vec4<real>* __restrict__ S,
+                                                vec4<real>* __restrict__ O) {
+  const int lp = blockIdx.x * 64 + threadIdx.x;   // point index inside the chunk (stash index)
+  const int pt = base + lp;                        // index into the point arrays
+  const int W = nd.width, H = nd.n_hidden;
+  const real x = xs[pt], t = ts[pt];
+  const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
+
+  {  // dense 0: inputs are (hx, ht); p0 = (sx, 0), q0 = (0, st), r0 = 0
+    const real* __restrict__ W0 = th + nd.off_w[0];
+    const real* __restrict__ b0 = th + nd.off_b[0];
+    for (int j = 0; j < W; ++j) {
+      const real w0 = W0[j], w1 = W0[W + j];
+      const real z = hx * w0 + ht * w1 + b0[j];
+      S[(size_t)j * s_pad + lp] = vec4<real>{tanh_r(z), sx * w0, st * w1, real(0)};
+    }
+  }
+  for (int d = 1; d < H; ++d) {
+    const real* __restrict__ Wd = th + nd.off_w[d];
+    const real* __restrict__ bd = th + nd.off_b[d];
+    const vec4<real>* __restrict__ Sin = S + (size_t)(d - 1) * W * s_pad + lp;
+    vec4<real>* __restrict__ Sout = S + (size_t)d * W * s_pad + lp;
+    for (int j0 = 0; j0 < W; j0 += JT) {
+      real az[JT], ap[JT], aq[JT], ar[JT];
+#pragma unroll
+      for (int jj = 0; jj < JT; ++jj) {
+        az[jj] = (j0 + jj < W) ? bd[j0 + jj] : real(0);
+        ap[jj] = aq[jj] = ar[jj] = real(0);
+      }
+      for (int k = 0; k < W; ++k) {
+        const vec4<real> s = Sin[(size_t)k * s_pad];
+        const real a = s.x, d1 = real(1) - a * a, d2 = real(-2) * a * d1;
+        const real p = d1 * s.y, q = d1 * s.z, r = d2 * s.y * s.y + d1 * s.w;
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) {
+          if (j0 + jj < W) {
+            const real w = Wd[k * W + j0 + jj];
+            az[jj] += a * w; ap[jj] += p * w; aq[jj] += q * w; ar[jj] += r * w;
+          }
+        }
+      }
+#pragma unroll
+      for (int jj = 0; jj < JT; ++jj)
+        if (j0 + jj < W)
+          Sout[(size_t)(j0 + jj) * s_pad] = vec4<real>{tanh_r(az[jj]), ap[jj], aq[jj], ar[jj]};
+    }
+  }
+  {  // linear output layer (dense H)
+    const real* __restrict__ WL = th + nd.off_w[H];
+    const real* __restrict__ bL = th + nd.off_b[H];
+    const vec4<real>* __restrict__ Sin = S + (size_t)(H - 1) * W * s_pad + lp;
+    real oz[2] = {bL[0], nd.n_out > 1 ? bL[1] : real(0)};
+    real op[2] = {0, 0}, oq[2] = {0, 0}, orr[2] = {0, 0};
+    for (int k = 0; k < W; ++k) {
+      const vec4<real> s = Sin[(size_t)k * s_pad];
+      const real a = s.x, d1 = real(1) - a * a, d2 = real(-2) * a * d1;
+      const real p = d1 * s.y, q = d1 * s.z, r = d2 * s.y * s.y + d1 * s.w;
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (o < nd.n_out) {
+          const real w = WL[k * nd.n_out + o];
+          oz[o] += a * w; op[o] += p * w; oq[o] += q * w; orr[o] += r * w;
+        }
+      }
+    }
+    for (int o = 0; o < nd.n_out; ++o)
+      O[(size_t)o * n_pad + pt] = vec4<real>{oz[o], op[o], oq[o], orr[o]};
+  }
+}
+
+// Point class of global point index g.
+enum { CLS_BLO = 0, CLS_BHI = 1, CLS_DATA = 2, CLS_COL = 3, CLS_PAD = 4 };
+__device__ __forceinline__ int point_class(const SetDesc& sd, int g) {
+  if (g < sd.n_b) return CLS_BLO;
+  if (g < 2 * sd.n_b) return CLS_BHI;
+  if (g < 2 * sd.n_b + sd.n_u) return CLS_DATA;
+  if (g < sd.n_all) return CLS_COL;
+  return CLS_PAD;
+}
+
+// Per-point loss contributions and output adjoints.
+//   sb[o] <- (h_bar, p_bar, q_bar, r_bar) of output o;  lt[0..2] <- (f, data, boundary) loss parts
+//   dl[0..1] <- d/d lambda_1, d/d lambda_2 contributions (identification only)
+template <typename real, int PDE>
+__device__ __forceinline__ void point_seeds(const SetDesc& sd, int g, int n_pad,
+                                            const vec4<real>* __restrict__ O,
+                                            const real* __restrict__ tgt, real c1, real c2,
+                                            vec4<real> sb[2], real lt[3], real dl[2]) {
+  const int cls = point_class(sd, g);
+  sb[0] = sb[1] = vec4<real>{0, 0, 0, 0};
+  lt[0] = lt[1] = lt[2] = real(0);
+  dl[0] = dl[1] = real(0);
+  if (cls == CLS_PAD) return;
+  const real inv_nf = (real)sd.inv_nf, inv_nu = (real)sd.inv_nu, inv_nb = (real)sd.inv_nb;
+  if (PDE == 0 || PDE == 1) {   // Burgers (inference / identification)
+    const vec4<real> o = O[g];
+    const bool res = (PDE == 0) ? (cls == CLS_COL) : (cls == CLS_DATA);
+    if (res) {
+      const real f = o.z + c1 * o.x * o.y - c2 * o.w;       // u_t + c1 u u_x - c2 u_xx
+      const real fb = real(2) * f * ((PDE == 0) ? inv_nf : inv_nu);
+      lt[0] = f * f * ((PDE == 0) ? inv_nf : inv_nu);
+      sb[0].x = fb * c1 * o.y; sb[0].y = fb * c1 * o.x; sb[0].z = fb; sb[0].w = -c2 * fb;
+      if (PDE == 1) { dl[0] = fb * o.x * o.y; dl[1] = -fb * c2 * o.w; }
+    }
+    if (cls == CLS_DATA) {
+      const real dd = o.x - tgt[g];
+      lt[1] = dd * dd * inv_nu;
+      sb[0].x += real(2) * dd * inv_nu;
+    }
+  } else {                      // Schrodinger
+    const vec4<real> ou = O[g], ov = O[(size_t)n_pad + g];
+    if (cls == CLS_COL) {
+      const real u = ou.x, v = ov.x, h2 = u * u + v * v;
+      const real fu = ou.z + real(0.5) * ov.w + h2 * v;     // u_t + v_xx/2 + |h|^2 v
+      const real fv = ov.z - real(0.5) * ou.w - h2 * u;     // v_t - u_xx/2 - |h|^2 u
+      lt[0] = (fu * fu + fv * fv) * inv_nf;
+      const real gu = real(2) * fu * inv_nf, gv = real(2) * fv * inv_nf;
+      sb[0].x = gu * real(2) * u * v - gv * (real(3) * u * u + v * v);
+      sb[1].x = gu * (u * u + real(3) * v * v) - gv * real(2) * u * v;
+      sb[0].z = gu; sb[1].z = gv;
+      sb[0].w = real(-0.5) * gv; sb[1].w = real(0.5) * gu;
+    } else if (cls == CLS_DATA) {
+      const real du = ou.x - tgt[g], dv = ov.x - tgt[(size_t)n_pad + g];
+      lt[1] = (du * du + dv * dv) * inv_nu;
+      sb[0].x = real(2) * du * inv_nu; sb[1].x = real(2) * dv * inv_nu;
+    } else {                    // periodic boundary pair (g in lo  <->  g + n_b in hi)
+      const int lo = (cls == CLS_BLO) ? g : g - sd.n_b, hi = lo + sd.n_b;
+      const vec4<real> ul = O[lo], uh = O[hi], vl = O[(size_t)n_pad + lo], vh = O[(size_t)n_pad + hi];
+      const real dhu = ul.x - uh.x, dhv = vl.x - vh.x, dpu = ul.y - uh.y, dpv = vl.y - vh.y;
+      const real sg = (cls == CLS_BLO) ? real(2) * inv_nb : real(-2) * inv_nb;
+      if (cls == CLS_BLO) lt[2] = (dhu * dhu + dhv * dhv + dpu * dpu + dpv * dpv) * inv_nb;
+      sb[0].x = sg * dhu; sb[1].x = sg * dhv; sb[0].y = sg * dpu; sb[1].y = sg * dpv;
+    }
+  }
+}
+
+template <typename real>
+__device__ __forceinline__ real dot4(const vec4<real>& a, const vec4<real>& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// layer-input channels (h,p,q,r) and tanh derivative factors from a stash entry
+template <typename real>
+__device__ __forceinline__ vec4<real> channels_of(const vec4<real>& s, real& d1, real& d2) {
+  const real a = s.x;
+  d1 = real(1) - a * a;
+  d2 = real(-2) * a * d1;
+  return vec4<real>{a, d1 * s.y, d1 * s.z, d2 * s.y * s.y + d1 * s.w};
+}
+
+// adjoint of the pre-activation channels from the adjoint of the output channels (A.3)
+template <typename real>
+__device__ __forceinline__ vec4<real> preact_adjoint(const vec4<real>& s, const vec4<real>& ob) {
+  const real a = s.x, d1 = real(1) - a * a, d2 = real(-2) * a * d1;
+  const real d3 = real(-2) * d1 * (real(1) - real(3) * a * a);
+  vec4<real> zb;
+  zb.x = d1 * ob.x + d2 * (s.y * ob.y + s.z * ob.z + s.w * ob.w) + d3 * s.y * s.y * ob.w;
+  zb.y = d1 * ob.y + real(2) * d2 * s.y * ob.w;
+  zb.z = d1 * ob.z;
+  zb.w = d1 * ob.w;
+  return zb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reverse sweep for one wave of 64 points.  Emits one partial-gradient row per wave:
+//   part[row*R + i], i < n_theta : sum over the wave's points of dL/dtheta_i
+//   part[row*R + n_theta + {0,1,2}] : loss parts (residual, data, boundary)
+// Rows are summed in fixed order by k_reduce_rows -> deterministic gradients.
+// ---------------------------------------------------------------------------------------------
+template <typename real, int PDE, int KT>
+__global__ __launch_bounds__(64) void k_backward(NetDesc nd, SetDesc sd,
+                                                 const real* __restrict__ th,
+                                                 const real* __restrict__ xs,
+                                                 const real* __restrict__ ts,
+                                                 const real* __restrict__ tgt, int base, int n_pad,
+                                                 int s_pad, real lbx, real lbt, real sx, real st,
+                                                 real nu, const vec4<real>* __restrict__ S,
+                                                 const vec4<real>* __restrict__ O,
+                                                 vec4<real>* __restrict__ ZA,
+                                                 vec4<real>* __restrict__ ZB,
+                                                 real* __restrict__ part, int R, int accumulate) {
+  const int lane = threadIdx.x;
+  const int lp = blockIdx.x * 64 + lane;
+  const int pt = base + lp;
+  const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
+  real* __restrict__ row = part + (size_t)blockIdx.x * R;
+
+  real c1 = real(1), c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp(th[nd.n_net + 1]); }
+
+  vec4<real> sb[2];
+  real lt[3], dl[2];
+  point_seeds<real, PDE>(sd, pt, n_pad, O, tgt, c1, c2, sb, lt, dl);
+
+  auto put = [&](int idx, real v) {   // lane-uniform idx; executed by one lane
+    row[idx] = accumulate ? row[idx] + v : v;
+  };
+  {
+    const real l0 = wave_sum(lt[0]), l1 = wave_sum(lt[1]), l2 = wave_sum(lt[2]);
+    if (lane == 0) { put(nd.n_theta + 0, l0); put(nd.n_theta + 1, l1); put(nd.n_theta + 2, l2); }
+    if (PDE == 1) {
+      const real g1 = wave_sum(dl[0]), g2 = wave_sum(dl[1]);
+      if (lane == 0) { put(nd.n_net, g1); put(nd.n_net + 1, g2); }
+    }
+  }
+
+  vec4<real>* __restrict__ Zcur = ZA;
+  vec4<real>* __restrict__ Znxt = ZB;
+
+  {  // dense H (linear output): z_bar = seeds
+    const real* __restrict__ WL = th + nd.off_w[H];
+    const vec4<real>* __restrict__ Sin = S + (size_t)(H - 1) * W * s_pad + lp;
+    real keep[4] = {0, 0, 0, 0};      // lane l keeps entries l, l+64, l+128, l+192 of W*NO (<= 256)
+    for (int k = 0; k < W; ++k) {
+      const vec4<real> s = Sin[(size_t)k * s_pad];
+      real d1, d2;
+      const vec4<real> in = channels_of(s, d1, d2);
+      vec4<real> ob{0, 0, 0, 0};
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        if (o < NO) {
+          const real g = wave_sum(dot4(in, sb[o]));
+          const int e = k * NO + o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) if ((e >> 6) == q && (e & 63) == lane) keep[q] = g;
+          const real w = WL[k * NO + o];
+          ob.x += sb[o].x * w; ob.y += sb[o].y * w; ob.z += sb[o].z * w; ob.w += sb[o].w * w;
+        }
+      }
+      Zcur[(size_t)k * s_pad + lp] = preact_adjoint(s, ob);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (q * 64 + lane < W * NO) put(nd.off_w[H] + q * 64 + lane, keep[q]);
+    for (int o = 0; o < NO; ++o) {
+      const real g = wave_sum(sb[o].x);
+      if (lane == 0) put(nd.off_b[H] + o, g);
+    }
+  }
+
+  for (int d = H - 1; d >= 1; --d) {
+    const real* __restrict__ Wd = th + nd.off_w[d];
+    const vec4<real>* __restrict__ Sin = S + (size_t)(d - 1) * W * s_pad + lp;
+    for (int k0 = 0; k0 < W; k0 += KT) {
+      vec4<real> sk[KT], in[KT], acc[KT];
+      real keep0[KT], keep1[KT], keepb0 = 0, keepb1 = 0;
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) {
+        const int k = (k0 + kk < W) ? k0 + kk : W - 1;
+        sk[kk] = Sin[(size_t)k * s_pad];
+        real d1, d2;
+        in[kk] = channels_of(sk[kk], d1, d2);
+        acc[kk] = vec4<real>{0, 0, 0, 0};
+        keep0[kk] = keep1[kk] = real(0);
+      }
+      for (int j = 0; j < W; ++j) {
+        const vec4<real> zb = Zcur[(size_t)j * s_pad + lp];
+        const bool mine = ((j & 63) == lane);
+        if (k0 == 0) {
+          const real g = wave_sum(zb.x);
+          if (mine) { if (j < 64) keepb0 = g; else keepb1 = g; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+          if (k0 + kk < W) {
+            const real g = wave_sum(dot4(in[kk], zb));
+            if (mine) { if (j < 64) keep0[kk] = g; else keep1[kk] = g; }
+            const real w = Wd[(k0 + kk) * W + j];
+            acc[kk].x += zb.x * w; acc[kk].y += zb.y * w; acc[kk].z += zb.z * w; acc[kk].w += zb.w * w;
+          }
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) {
+        if (k0 + kk < W) {
+          const int o = nd.off_w[d] + (k0 + kk) * W;
+          if (lane < W) put(o + lane, keep0[kk]);
+          if (lane + 64 < W) put(o + lane + 64, keep1[kk]);
+          Znxt[(size_t)(k0 + kk) * s_pad + lp] = preact_adjoint(sk[kk], acc[kk]);
+        }
+      }
+      if (k0 == 0) {
+        if (lane < W) put(nd.off_b[d] + lane, keepb0);
+        if (lane + 64 < W) put(nd.off_b[d] + lane + 64, keepb1);
+      }
+    }
+    vec4<real>* tmp = Zcur; Zcur = Znxt; Znxt = tmp;
+  }
+
+  {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st), r0 = 0
+    const real x = xs[pt], t = ts[pt];
+    const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
+    real kx0 = 0, kx1 = 0, kt0 = 0, kt1 = 0, kb0 = 0, kb1 = 0;
+    for (int j = 0; j < W; ++j) {
+      const vec4<real> zb = Zcur[(size_t)j * s_pad + lp];
+      const real gx = wave_sum(hx * zb.x + sx * zb.y);
+      const real gt = wave_sum(ht * zb.x + st * zb.z);
+      const real gb = wave_sum(zb.x);
+      if ((j & 63) == lane) {
+        if (j < 64) { kx0 = gx; kt0 = gt; kb0 = gb; } else { kx1 = gx; kt1 = gt; kb1 = gb; }
+      }
+    }
+    if (lane < W) { put(nd.off_w[0] + lane, kx0); put(nd.off_w[0] + W + lane, kt0); put(nd.off_b[0] + lane, kb0); }
+    if (lane + 64 < W) { put(nd.off_w[0] + lane + 64, kx1); put(nd.off_w[0] + W + lane + 64, kt1); put(nd.off_b[0] + lane + 64, kb1); }
+  }
+}
+
+// PDE residual at stored points from the forward outputs (f_model()).
+template <typename real, int PDE>
+__global__ void k_residual(int first, int n, int n_pad, const vec4<real>* __restrict__ O,
+                           const real* __restrict__ th, int n_net, real nu,
+                           double* __restrict__ f, int n_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = first + i;
+  if (PDE == 2) {
+    const vec4<real> ou = O[g], ov = O[(size_t)n_pad + g];
+    const real u = ou.x, v = ov.x, h2 = u * u + v * v;
+    f[(size_t)i * 2 + 0] = (double)(ou.z + real(0.5) * ov.w + h2 * v);
+    f[(size_t)i * 2 + 1] = (double)(ov.z - real(0.5) * ou.w - h2 * u);
+  } else {
+    real c1 = real(1), c2 = nu;
+    if (PDE == 1) { c1 = th[n_net]; c2 = exp(th[n_net + 1]); }
+    const vec4<real> o = O[g];
+    f[i] = (double)(o.z + c1 * o.x * o.y - c2 * o.w);
+  }
+}
+
+}  // namespace pinn

@@ -1,0 +1,229 @@
+// kernels_optim.h -- deterministic gradient reduction, Adam, device-resident L-BFGS.
+// All optimiser state is float64 whatever the kernel compute dtype (the reference is
+// float64 end to end, utils/neuralnetwork.py:24-26); the compute kernels read a `real`
+// mirror of the weights that these kernels keep in sync.
+#pragma once
+#include "wave.h"
+
+namespace pinn {
+
+// gl[c] = sum over rows of part[row*R + c], rows added in index order (bit-reproducible).
+// gl layout: [0, n_theta) gradient | n_theta+0..2 loss parts (residual, data, boundary).
+template <typename real>
+__global__ void k_reduce_rows(const real* __restrict__ part, int n_rows, int R,
+                              double* __restrict__ gl) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= R) return;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int r = 0;
+  for (; r + 3 < n_rows; r += 4) {
+    s0 += (double)part[(size_t)(r + 0) * R + c];
+    s1 += (double)part[(size_t)(r + 1) * R + c];
+    s2 += (double)part[(size_t)(r + 2) * R + c];
+    s3 += (double)part[(size_t)(r + 3) * R + c];
+  }
+  for (; r < n_rows; ++r) s0 += (double)part[(size_t)r * R + c];
+  gl[c] = (s0 + s1) + (s2 + s3);
+}
+
+// TF-2.0 ResourceApplyAdam (reference call site
+// utils/neuralnetwork.py:114): m += (1-b1)(g-m); v += (1-b2)(g^2-v);
+// theta -= alpha*m/(sqrt(v)+eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host.
+template <typename real>
+__global__ void k_adam(int n, const double* __restrict__ gl, double* __restrict__ theta,
+                       real* __restrict__ theta_r, double* __restrict__ m,
+                       double* __restrict__ v, double alpha, double b1, double b2, double eps,
+                       double* __restrict__ loss_slot, int n_theta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && loss_slot) *loss_slot = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
+  if (i >= n) return;
+  const double g = gl[i];
+  const double mi = m[i] + (1.0 - b1) * (g - m[i]);
+  const double vi = v[i] + (1.0 - b2) * (g * g - v[i]);
+  m[i] = mi;
+  v[i] = vi;
+  const double t = theta[i] - alpha * mi / (sqrt(vi) + eps);
+  theta[i] = t;
+  theta_r[i] = (real)t;
+}
+
+template <typename real>
+__global__ void k_cast_weights(int n, const double* __restrict__ theta, real* __restrict__ theta_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) theta_r[i] = (real)theta[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// L-BFGS (utils/custom_lbfgs.py:39-236), one 1024-thread workgroup, float64.
+// ---------------------------------------------------------------------------------------------
+struct LbfgsState {
+  int n_iter;        // state.nIter
+  int func_eval;     // currentFuncEval
+  int hist_len;      // len(old_dirs)
+  int hist_head;     // ring index of the oldest pair
+  int done;          // 0 running | 1 nIter==maxIter | 2 gtd>-tolX | 3 maxEval | 4 tolFun | 5 step<tolX | 6 |df|<tolX | 7 initial tolFun
+  int n_logged;      // log_fn calls so far
+  int pad0, pad1;
+  double Hdiag, t, f, f_old, final_loss;
+};
+
+constexpr int LB_THREADS = 1024;
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  // fixed-shape reduction: wave DPP sum, then the 16 wave totals in index order
+  const double w = wave_sum(v);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[wid] = w;
+  __syncthreads();
+  double tot = 0;
+#pragma unroll
+  for (int i = 0; i < LB_THREADS / 64; ++i) tot += sh[i];
+  return tot;
+}
+
+// Compute the search direction, step, and advance x (custom_lbfgs.py:84-174).
+//   g    : gradient at the current x (= gl from the last evaluation)
+//   x    : L-BFGS iterate;  theta/theta_r: model weights (set only when an evaluation follows,
+//          i.e. when nIter != maxIter -- custom_lbfgs.py:176 + neuralnetwork.py:94)
+template <typename real>
+__global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
+    int n, int max_iter, int n_corr, double lr, double tol_x, LbfgsState* __restrict__ st,
+    const double* __restrict__ g, double* __restrict__ x, double* __restrict__ theta,
+    real* __restrict__ theta_r, double* __restrict__ d, double* __restrict__ g_old,
+    double* __restrict__ Sh, double* __restrict__ Yh, double* __restrict__ ro,
+    double* __restrict__ al, double* __restrict__ q) {
+  __shared__ double sh[LB_THREADS / 64];
+  __shared__ int s_flag;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  const int n_iter = st->n_iter + 1;
+  int hist_len = st->hist_len, head = st->hist_head;
+  double Hdiag = st->Hdiag;
+  const double t_prev = st->t;
+
+  if (n_iter == 1) {                                   // :90-95
+    for (int i = tid; i < n; i += LB_THREADS) d[i] = -g[i];
+    hist_len = 0; head = 0; Hdiag = 1.0;
+  } else {
+    // y = g - g_old, s = d*t  (:98-100); staged in q (y) and al-free scratch d stays d
+    double ys_p = 0, yy_p = 0;
+    for (int i = tid; i < n; i += LB_THREADS) {
+      const double y = g[i] - g_old[i], s = d[i] * t_prev;
+      ys_p += y * s; yy_p += y * y;
+    }
+    const double ys = block_sum(ys_p, sh);
+    const double yy = block_sum(yy_p, sh);
+    if (ys > 1e-10) {                                  // :102-114
+      int slot;
+      if (hist_len == n_corr) { slot = head; head = (head + 1) % n_corr; }
+      else { slot = (head + hist_len) % n_corr; hist_len += 1; }
+      for (int i = tid; i < n; i += LB_THREADS) {
+        Sh[(size_t)slot * n + i] = d[i] * t_prev;
+        Yh[(size_t)slot * n + i] = g[i] - g_old[i];
+      }
+      if (tid == 0) ro[slot] = 1.0 / ys;               // 1/dot(old_stps[i], old_dirs[i]) (:121-123)
+      Hdiag = ys / yy;
+    }
+    __syncthreads();
+    // two-loop recursion (:126-141); logical index i -> ring slot (head+i)%n_corr
+    for (int i = tid; i < n; i += LB_THREADS) q[i] = -g[i];
+    __syncthreads();
+    for (int li = hist_len - 1; li >= 0; --li) {
+      const int slot = (head + li) % n_corr;
+      double p = 0;
+      for (int i = tid; i < n; i += LB_THREADS) p += Sh[(size_t)slot * n + i] * q[i];
+      const double a = block_sum(p, sh) * ro[slot];
+      if (tid == 0) al[slot] = a;
+      for (int i = tid; i < n; i += LB_THREADS) q[i] -= a * Yh[(size_t)slot * n + i];
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += LB_THREADS) q[i] *= Hdiag;          // r = q*Hdiag
+    __syncthreads();
+    for (int li = 0; li < hist_len; ++li) {
+      const int slot = (head + li) % n_corr;
+      double p = 0;
+      for (int i = tid; i < n; i += LB_THREADS) p += Yh[(size_t)slot * n + i] * q[i];
+      const double be = block_sum(p, sh) * ro[slot];
+      const double co = al[slot] - be;
+      for (int i = tid; i < n; i += LB_THREADS) q[i] += co * Sh[(size_t)slot * n + i];
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += LB_THREADS) d[i] = q[i];
+  }
+  __syncthreads();
+  // g_old = g, f_old = f  (:143-145); gtd = g.d (:151)
+  double gtd_p = 0, ga_p = 0;
+  for (int i = tid; i < n; i += LB_THREADS) {
+    const double gi = g[i];
+    g_old[i] = gi;
+    gtd_p += gi * d[i];
+    ga_p += fabs(gi);
+  }
+  const double gtd = block_sum(gtd_p, sh);
+  const double gabs = block_sum(ga_p, sh);
+  if (tid == 0) s_flag = (gtd > -tol_x) ? 1 : 0;       // :154-156
+  __syncthreads();
+  if (s_flag) {
+    if (tid == 0) {
+      st->n_iter = n_iter; st->hist_len = hist_len; st->hist_head = head; st->Hdiag = Hdiag;
+      st->f_old = st->f; st->done = 2;
+    }
+    return;
+  }
+  double t;                                            // :159-163
+  if (n_iter == 1) { const double inv = 1.0 / gabs; t = inv < 1.0 ? inv : 1.0; }
+  else t = lr;
+  const bool will_eval = (n_iter != max_iter);         // :176
+  for (int i = tid; i < n; i += LB_THREADS) {
+    const double xi = x[i] + t * d[i];                 // :174
+    x[i] = xi;
+    if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; }
+  }
+  if (tid == 0) {
+    st->n_iter = n_iter; st->hist_len = hist_len; st->hist_head = head; st->Hdiag = Hdiag;
+    st->t = t; st->f_old = st->f;
+    if (!will_eval) st->done = 1;                      // :192 (nIter == maxIter)
+  }
+}
+
+// After the re-evaluation: bookkeeping and the break tests of custom_lbfgs.py:185-224.
+__global__ __launch_bounds__(LB_THREADS) void k_lbfgs_post(
+    int n, int n_theta, int max_iter, double max_eval, double tol_fun, double tol_x,
+    LbfgsState* __restrict__ st, const double* __restrict__ gl, const double* __restrict__ d,
+    int* __restrict__ log_iters, double* __restrict__ log_losses, int initial) {
+  __shared__ double sh[LB_THREADS / 64];
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  const double f = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
+  double ga_p = 0, sa_p = 0;
+  const double t = st->t;
+  for (int i = tid; i < n; i += LB_THREADS) {
+    ga_p += fabs(gl[i]);
+    if (!initial) sa_p += fabs(d[i] * t);
+  }
+  const double gabs = block_sum(ga_p, sh);
+  const double sabs = block_sum(sa_p, sh);
+  if (tid != 0) return;
+  if (initial) {                                       // :65-76
+    st->f = f; st->func_eval = 1;
+    if (gabs <= tol_fun) st->done = 7;
+    return;
+  }
+  const double f_old = st->f_old;
+  st->f = f;
+  st->func_eval += 1;
+  const int n_iter = st->n_iter;
+  if (n_iter == max_iter) { st->done = 1; return; }    // :192 (unreachable: step sets it)
+  if ((double)st->func_eval >= max_eval) { st->done = 3; return; }   // :195
+  if (gabs <= tol_fun) { st->done = 4; return; }       // :200-203
+  if (sabs <= tol_x) { st->done = 5; return; }         // :206-209
+  if (fabs(f - f_old) < tol_x) { st->done = 6; return; }   // :212-215
+  const int k = st->n_logged;                          // :217-218
+  log_iters[k] = n_iter;
+  log_losses[k] = f;
+  st->n_logged = k + 1;
+  if (n_iter == max_iter - 1) st->final_loss = f;      // :223-224
+}
+
+}  // namespace pinn

@@ -1,0 +1,321 @@
+"""ctypes binding of libpinn_hip.so (C ABI: include/pinn_hip.h) -- the only way the Python
+host reaches the GPU.  There is deliberately no CPU fallback: if the HIP library cannot be
+loaded or no device is present, construction fails with an explicit error.
+
+    from pinn_native import Engine, build
+    eng = Engine(layers, lb, ub, pde="burgers", dtype="f32")
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+LIB_PATH = os.path.join(_HERE, "libpinn_hip.so")
+SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_optim.h", "wave.h"]
+HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
+
+PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2}
+DTYPES = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class PinnNativeError(RuntimeError):
+    pass
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    srcs = [os.path.join(_CSRC, s) for s in SOURCES] + [HEADER]
+    return any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP engine for gfx950 into pinn_native/libpinn_hip.so (in-tree, so the
+    shared object travels with the repo snapshot).  hipcc cross-compiles without a GPU."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           os.path.join(_CSRC, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise PinnNativeError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_LIB = None
+
+_SIGNATURES = {
+    "pinn_last_error": (ctypes.c_char_p, []),
+    "pinn_abi_version": (ctypes.c_int, []),
+    "pinn_device_count": (ctypes.c_int, [_c_int_p]),
+    "pinn_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int, _c_int_p,
+                                        ctypes.POINTER(ctypes.c_int64)]),
+    "pinn_create": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _c_int_p, ctypes.c_int,
+                                   _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int]),
+    "pinn_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "pinn_num_params": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]),
+    "pinn_set_collocation": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64,
+                                            ctypes.c_int64]),
+    "pinn_set_data": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.c_int64,
+                                     ctypes.c_int64]),
+    "pinn_set_boundary": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p,
+                                         ctypes.c_int64, ctypes.c_int64]),
+    "pinn_set_pde_params": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int]),
+    "pinn_set_weights": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_get_weights": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_loss_grad": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
+    "pinn_adam_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_double]),
+    "pinn_adam_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p]),
+    "pinn_lbfgs_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                        ctypes.c_double]),
+    "pinn_lbfgs_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p, _c_double_p,
+                                      _c_int_p, _c_int_p]),
+    "pinn_lbfgs_get_x": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
+    "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
+    "pinn_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int,
+                                      ctypes.c_int]),
+    "pinn_timing_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pinn_timing_read": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_int_p]),
+    "pinn_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "pinn_set_kernel_path": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pinn_get_kernel_path": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
+}
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def load():
+    """dlopen the engine (building it first if the sources are newer and hipcc exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if _stale():
+        try:
+            build()
+        except PinnNativeError:
+            if not os.path.exists(LIB_PATH):
+                raise
+    if not os.path.exists(LIB_PATH):
+        raise PinnNativeError(
+            "libpinn_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; "
+            "g.build()'`.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    lib = load()
+    if lib.pinn_device_count(ctypes.byref(n)) != 0:
+        return 0
+    return n.value
+
+
+def device_info(device=0):
+    lib = load()
+    buf = ctypes.create_string_buffer(256)
+    ncu = ctypes.c_int(0)
+    mem = ctypes.c_int64(0)
+    if lib.pinn_device_info(device, buf, 256, ctypes.byref(ncu), ctypes.byref(mem)) != 0:
+        raise PinnNativeError(lib.pinn_last_error().decode())
+    return {"name": buf.value.decode(), "compute_units": ncu.value, "hbm_bytes": mem.value}
+
+
+class Engine(object):
+    """One engine context = one GPU, one stream, one network + training set."""
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f32", device=0):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        if pde not in PDE_KINDS:
+            raise ValueError("pde must be one of %s" % sorted(PDE_KINDS))
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be one of %s" % sorted(DTYPES))
+        self.layers = [int(v) for v in layers]
+        self.pde, self.dtype = pde, ("f64" if DTYPES[dtype] else "f32")
+        self.n_out = self.layers[-1]
+        arr = (ctypes.c_int * len(self.layers))(*self.layers)
+        lb, ub = _f64(lb, (2,)), _f64(ub, (2,))
+        self._check(self._lib.pinn_create(ctypes.byref(self._h), arr, len(self.layers), _dp(lb),
+                                          _dp(ub), PDE_KINDS[pde], DTYPES[dtype], int(device)))
+        n = ctypes.c_int64(0)
+        self._check(self._lib.pinn_num_params(self._h, ctypes.byref(n)))
+        self.n_params = n.value
+        self.n_f = self.n_u = self.n_b = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PinnNativeError("libpinn_hip: %s (code %d)" % (
+                self._lib.pinn_last_error().decode(errors="replace"), rc))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pinn_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- point sets ----------------------------------------------------------------------
+    def set_collocation(self, X_f, n_total=None):
+        X_f = _f64(X_f).reshape(-1, 2)
+        self.n_f = X_f.shape[0]
+        self._check(self._lib.pinn_set_collocation(self._h, _dp(X_f), self.n_f,
+                                                   self.n_f if n_total is None else int(n_total)))
+
+    def set_data(self, X_u, u, n_total=None):
+        X_u = _f64(X_u).reshape(-1, 2)
+        u = _f64(u).reshape(X_u.shape[0], self.n_out)
+        self.n_u = X_u.shape[0]
+        self._check(self._lib.pinn_set_data(self._h, _dp(X_u), _dp(u), self.n_u,
+                                            self.n_u if n_total is None else int(n_total)))
+
+    def set_boundary(self, X_lb, X_ub, n_total=None):
+        X_lb, X_ub = _f64(X_lb).reshape(-1, 2), _f64(X_ub).reshape(-1, 2)
+        if X_lb.shape != X_ub.shape:
+            raise ValueError("X_lb and X_ub must pair up")
+        self.n_b = X_lb.shape[0]
+        self._check(self._lib.pinn_set_boundary(self._h, _dp(X_lb), _dp(X_ub), self.n_b,
+                                                self.n_b if n_total is None else int(n_total)))
+
+    def set_pde_params(self, *p):
+        p = _f64(p)
+        self._check(self._lib.pinn_set_pde_params(self._h, _dp(p), p.size))
+
+    # ---- weights ---------------------------------------------------------------------------
+    def set_weights(self, w):
+        w = _f64(w).ravel()
+        self._check(self._lib.pinn_set_weights(self._h, _dp(w), w.size))
+
+    def get_weights(self):
+        w = np.empty(self.n_params, dtype=np.float64)
+        self._check(self._lib.pinn_get_weights(self._h, _dp(w), w.size))
+        return w
+
+    # ---- evaluation ------------------------------------------------------------------------
+    def loss_grad(self, want_grad=True):
+        loss = ctypes.c_double(0.0)
+        terms = np.zeros(3, dtype=np.float64)
+        grad = np.empty(self.n_params, dtype=np.float64) if want_grad else None
+        self._check(self._lib.pinn_loss_grad(self._h, ctypes.byref(loss),
+                                             _dp(grad) if want_grad else None, _dp(terms)))
+        return loss.value, grad, terms
+
+    def predict(self, X):
+        X = _f64(X).reshape(-1, 2)
+        out = np.empty((X.shape[0], self.n_out), dtype=np.float64)
+        self._check(self._lib.pinn_predict(self._h, _dp(X), X.shape[0], _dp(out)))
+        return out
+
+    def residual(self):
+        n = self.n_u if self.pde == "burgers_ide" else self.n_f
+        f = np.empty((n, self.n_out), dtype=np.float64)
+        self._check(self._lib.pinn_residual(self._h, _dp(f), n))
+        return f
+
+    # ---- optimisers ------------------------------------------------------------------------
+    def adam_init(self, lr, beta1=0.9, beta2=0.999, eps=1e-7):
+        self._check(self._lib.pinn_adam_init(self._h, lr, beta1, beta2, eps))
+
+    def adam_run(self, n_steps, want_losses=True):
+        if not want_losses:
+            self._check(self._lib.pinn_adam_run(self._h, int(n_steps), None))
+            return None
+        losses = np.empty(max(int(n_steps), 1), dtype=np.float64)
+        self._check(self._lib.pinn_adam_run(self._h, int(n_steps), _dp(losses)))
+        return losses[:n_steps]
+
+    def lbfgs_begin(self, max_iter, lr, n_corr, tol_fun, tol_x=1e-19, max_eval=0.0):
+        self._lb_max_iter = int(max_iter)
+        self._check(self._lib.pinn_lbfgs_begin(self._h, int(max_iter), lr, int(n_corr), tol_fun,
+                                               tol_x, max_eval))
+
+    def lbfgs_run(self, n_iters):
+        cap = max(int(n_iters), 1)
+        iters = np.zeros(cap, dtype=np.int32)
+        losses = np.zeros(cap, dtype=np.float64)
+        n_logged, done = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.pinn_lbfgs_run(self._h, int(n_iters),
+                                             iters.ctypes.data_as(_c_int_p), _dp(losses),
+                                             ctypes.byref(n_logged), ctypes.byref(done)))
+        k = n_logged.value
+        return iters[:k].copy(), losses[:k].copy(), done.value
+
+    def lbfgs_x(self):
+        x = np.empty(self.n_params, dtype=np.float64)
+        self._check(self._lib.pinn_lbfgs_get_x(self._h, _dp(x), x.size))
+        return x
+
+    # ---- multi-GPU -------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        lib = load()
+        buf = ctypes.create_string_buffer(128)
+        if lib.pinn_comm_unique_id(buf) != 0:
+            raise PinnNativeError(lib.pinn_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        self._check(self._lib.pinn_comm_init(self._h, bytes(unique_id), int(n_ranks), int(rank)))
+
+    # ---- measurement -----------------------------------------------------------------------
+    def timing_enable(self, max_evals):
+        self._check(self._lib.pinn_timing_enable(self._h, int(max_evals)))
+
+    def timing_read(self):
+        ms = np.zeros(3, dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._check(self._lib.pinn_timing_read(self._h, _dp(ms), ctypes.byref(n)))
+        return {"fwd_ms": ms[0], "sweeps_ms": ms[1], "eval_ms": ms[2], "n": n.value}
+
+    def sync(self):
+        self._check(self._lib.pinn_sync(self._h))
+
+    def set_kernel_path(self, path):
+        self._check(self._lib.pinn_set_kernel_path(self._h, int(path)))
+
+    def kernel_path(self):
+        p = ctypes.c_int(0)
+        self._check(self._lib.pinn_get_kernel_path(self._h, ctypes.byref(p)))
+        return p.value

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pinns-tf2.0_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "utils"), os.path.join(PKG, "1d-burgers"),
+          os.path.join(PKG, "1dcomplex-schrodinger")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+BURGERS_MAT = os.path.join(PKG, "1d-burgers", "data", "burgers_shock.mat")
+NLS_MAT = os.path.join(PKG, "1dcomplex-schrodinger", "data", "NLS.mat")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden(name):
+    return os.path.join(GOLDEN, name)
+
+
+@pytest.fixture(scope="session")
+def burgers_sets():
+    """{(N_u, N_f): prep_data tuple} for the seeds the goldens were generated with."""
+    import burgersutil
+    cache = {}
+
+    def get(N_u, N_f):
+        key = (N_u, N_f)
+        if key not in cache:
+            np.random.seed(1234)
+            cache[key] = burgersutil.prep_data(BURGERS_MAT, N_u, N_f, noise=0.0)
+        return cache[key]
+    return get
+
+
+@pytest.fixture(scope="session")
+def schrodinger_sets():
+    import schrodingerutil
+    cache = {}
+
+    def get(N_0, N_b, N_f):
+        key = (N_0, N_b, N_f)
+        if key not in cache:
+            np.random.seed(1234)
+            cache[key] = schrodingerutil.prep_data(NLS_MAT, N_0, N_b, N_f, noise=0.0)
+        return cache[key]
+    return get

@@ -1,0 +1,196 @@
+"""GPU parity tests (pytest -m gpu): HIP engine, through the C ABI, vs the CPU oracle and the
+golden fixtures produced by the reference's own Python (tests/golden/make_golden.py).
+
+Tolerances (relative to the gradient's max-abs unless noted):
+  f64 kernels: 1e-11    f32 kernels: 2e-5 (loss 1e-5)
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+NU = 0.01 / np.pi
+TOL = {"f64": dict(loss=1e-12, grad=1e-11), "f32": dict(loss=1e-5, grad=2e-5)}
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def make_burgers(sets, N_u, N_f, dtype, path=None):
+    from pinn_native import Engine
+    r = sets(N_u, N_f)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    layers = [2] + [20] * 8 + [1]
+    eng = Engine(layers, lb, ub, pde="burgers", dtype=dtype)
+    eng.set_collocation(X_f)
+    eng.set_data(X_u, u)
+    eng.set_pde_params(NU)
+    if path is not None:
+        try:
+            eng.set_kernel_path(path)
+        except Exception as e:                      # fused path not built for this shape
+            eng.close()
+            pytest.skip("kernel path %d unavailable: %s" % (path, e))
+    return eng, layers, (lb, ub, X_f, X_u, u)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
+def test_burgers_eval_vs_golden_and_oracle(burgers_sets, dtype, path, tag, N_u, N_f):
+    from oracle import pde
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, N_u, N_f, dtype, path)
+    eng.set_weights(g["w0"])
+    assert np.array_equal(eng.get_weights(), g["w0"])
+    loss, grad, terms = eng.loss_grad()
+    tol = TOL[dtype]
+    # golden = reference's own loss/grad code run over the test shim
+    assert abs(loss - float(g["loss"])) / float(g["loss"]) < tol["loss"]
+    assert rel(grad, g["grad"]) < tol["grad"]
+    assert abs(terms[1] - float(g["mse_u"])) / float(g["mse_u"]) < tol["loss"] * 10
+    # oracle at a second, non-trivial weight vector (biases non-zero)
+    rs = np.random.RandomState(7)
+    w1 = g["w0"] + 0.05 * rs.standard_normal(g["w0"].size)
+    eng.set_weights(w1)
+    loss, grad, _ = eng.loss_grad()
+    lo, go, ex = pde.burgers_loss_grad(w1, layers, lb, ub, X_f, X_u, u, NU)
+    assert abs(loss - lo) / lo < tol["loss"]
+    assert rel(grad, go) < tol["grad"]
+    f = eng.residual()
+    assert rel(f, ex["f"]) < tol["grad"] * 10
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_burgers_predict(burgers_sets, dtype):
+    from oracle import mlp
+    g = np.load(golden("burgers_eval.npz"))
+    eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, 100, 10000, dtype)
+    eng.set_weights(g["w0"])
+    X_star, u_star = burgers_sets(100, 10000)[5], burgers_sets(100, 10000)[6]
+    up = eng.predict(X_star)
+    assert up.shape == (25600, 1)
+    tol = 1e-12 if dtype == "f64" else 2e-6
+    assert np.max(np.abs(up[:64, 0] - g["u_pred_first"])) < tol
+    assert np.max(np.abs(up[::257, 0] - g["u_pred_stride"])) < tol
+    err0 = np.linalg.norm(u_star - up, 2) / np.linalg.norm(u_star, 2)
+    assert abs(err0 - float(g["err0"])) < tol * 10
+    # ragged sizes: 1 point, 65 points
+    for n in (1, 65):
+        assert np.max(np.abs(eng.predict(X_star[:n]) - mlp.forward_value(
+            mlp.unpack(g["w0"], layers), X_star[:n], lb, ub))) < tol
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
+def test_burgers_adam_trajectory(burgers_sets, dtype, tag, N_u, N_f):
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    ga = np.load(golden("burgers_adam%s.npz" % tag))
+    hp = json.loads(str(ga["hp"]))
+    eng, *_ = make_burgers(burgers_sets, N_u, N_f, dtype)
+    eng.set_weights(g["w0"])
+    eng.adam_init(hp["tf_lr"], hp["tf_b1"], 0.999, 1e-7)
+    l1 = eng.adam_run(1)
+    w1 = eng.get_weights()
+    l4 = eng.adam_run(4)
+    w5 = eng.get_weights()
+    l25 = eng.adam_run(25)
+    losses = np.concatenate([l1, l4, l25])
+    if dtype == "f64":
+        assert rel(w1, ga["w_after_1"]) < 1e-12
+        assert rel(w5, ga["w_after_5"]) < 1e-10
+        assert np.max(np.abs(losses - ga["losses"]) / ga["losses"]) < 1e-8
+        assert rel(eng.get_weights(), ga["w_after_30"]) < 1e-7
+    else:
+        # Adam's m/(sqrt(v)+eps) turns f32 gradient roundoff into O(lr*1e-4) weight differences
+        # on the first step; the trajectory stays close over 30 steps
+        assert rel(w1, ga["w_after_1"]) < 1e-3
+        assert np.max(np.abs(losses[:5] - ga["losses"][:5]) / ga["losses"][:5]) < 2e-2
+    eng.close()
+
+
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
+def test_burgers_lbfgs_trajectory_f64(burgers_sets, tag, N_u, N_f):
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    gl = np.load(golden("burgers_lbfgs%s.npz" % tag))
+    eng, *_ = make_burgers(burgers_sets, N_u, N_f, "f64")
+    eng.set_weights(g["w0"])
+    eng.lbfgs_begin(int(gl["max_iter"]), float(gl["lr"]), int(gl["n_corr"]), np.finfo(float).eps)
+    it_all, lo_all, done = [], [], 0
+    while not done:
+        it, lo, done = eng.lbfgs_run(7)        # odd chunking on purpose
+        it_all.extend(it.tolist())
+        lo_all.extend(lo.tolist())
+    assert done == 1
+    assert it_all == gl["log_iters"].tolist()                   # nIter = 1..maxIter-1
+    assert np.max(np.abs(np.array(lo_all) - gl["log_losses"]) / gl["log_losses"]) < 1e-8
+    # the quirk: model weights = last evaluated x, returned x is one step further
+    assert rel(eng.get_weights(), gl["w_model"]) < 1e-7
+    assert rel(eng.lbfgs_x(), gl["x_returned"]) < 1e-7
+    assert not np.allclose(eng.get_weights(), eng.lbfgs_x())
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_burgers_ide_eval(dtype, tag):
+    import burgersutil
+    from conftest import BURGERS_MAT
+    from oracle import pde
+    from pinn_native import Engine
+    g = np.load(golden("burgers_ide_eval%s.npz" % tag))
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.0)
+    X_u, u, ub, lb = r[7], r[8], r[9], r[10]
+    layers = [2] + [20] * 8 + [1]
+    eng = Engine(layers, lb, ub, pde="burgers_ide", dtype=dtype)
+    assert eng.n_params == 3023
+    eng.set_data(X_u, u)
+    eng.set_weights(g["w0"])
+    loss, grad, _ = eng.loss_grad()
+    tol = TOL[dtype]
+    assert abs(loss - float(g["loss"])) / float(g["loss"]) < tol["loss"]
+    assert rel(grad[:-2], g["grad"][:-2]) < tol["grad"]
+    assert abs(grad[-2] - g["grad"][-2]) < tol["grad"] * abs(g["grad"][-2]) * 50
+    assert abs(grad[-1] - g["grad"][-1]) < tol["grad"] * abs(g["grad"][-1]) * 50
+    lo, go, ex = pde.burgers_ide_loss_grad(g["w0"], layers, lb, ub, X_u, u)
+    assert rel(eng.residual(), ex["f"]) < tol["grad"] * 10
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,N_f", [("_small", 1024), ("", 20000)])
+def test_schrodinger_eval(schrodinger_sets, dtype, tag, N_f):
+    from pinn_native import Engine
+    g = np.load(golden("schrodinger_eval%s.npz" % tag))
+    hp = json.loads(str(g["hp"]))
+    r = schrodinger_sets(50, 50, N_f)
+    X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
+    X_lb = np.concatenate((0 * tb + lb[0], tb), 1)
+    X_ub = np.concatenate((0 * tb + ub[0], tb), 1)
+    uv0 = np.concatenate([u0, v0], 1)
+    eng = Engine(hp["layers"], lb, ub, pde="schrodinger", dtype=dtype)
+    eng.set_collocation(X_f)
+    eng.set_boundary(X_lb, X_ub)
+    tol = TOL[dtype]
+    for mode, Xin in (("compat", np.concatenate([x0, x0], 1)), ("intent", X0)):
+        eng.set_data(Xin, uv0)
+        eng.set_weights(g["w0"])
+        loss, grad, terms = eng.loss_grad()
+        assert abs(loss - float(g["loss_" + mode])) / float(g["loss_" + mode]) < tol["loss"]
+        assert rel(grad, g["grad_" + mode]) < tol["grad"]
+    f = eng.residual()
+    assert np.max(np.abs(f[:64, 0] - g["f_u_first"])) < tol["grad"] * 10
+    assert np.max(np.abs(f[:64, 1] - g["f_v_first"])) < tol["grad"] * 10
+    X_star = r[7]
+    uv = eng.predict(X_star)
+    assert np.max(np.abs(uv[::517, 0] - g["u_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
+    assert np.max(np.abs(uv[::517, 1] - g["v_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
+    eng.close()
