@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- collocation-points/sec of the PINN hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|f64] [--nf-per-gpu M]
+
+A *step* is one optimiser iteration = one full-batch pass of the hot path (Taylor-mode forward
+over every collocation point, PDE residual, loss reduction, flat gradient, optimiser update)
+over the rank's shard.  The workload is BASELINE.json configs[1]: 1D Burgers continuous
+inference, 8x20 tanh MLP, N_u=100, N_f=10000 *per GPU* (weak scaling; at N=1 this is exactly the
+reference configuration), Adam then L-BFGS in the reference's 1:2 proportion (100:200 default
+epochs, 1d-burgers/inf_cont_burgers.py:35-41).  Inputs are resident in HBM before the timed
+region.  W untimed warm-up steps, then exactly K timed steps bracketed by barrier +
+stream sync, MAX over ranks; rank 0 prints one JSON line.
+
+Launched by the driver for N>1 as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+(one process per GPU; gloo is used only to exchange the RCCL unique id and the timings,
+the gradient all-reduce itself is RCCL inside the engine).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "pinns-tf2.0_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "utils"), os.path.join(PKG, "1d-burgers")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+LAYERS = [2, 20, 20, 20, 20, 20, 20, 20, 20, 1]
+M_W = sum(a * b for a, b in zip(LAYERS[:-1], LAYERS[1:]))          # 2860 MACs per channel
+NU = 0.01 / np.pi
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}                          # MI355X_MICROARCH.md (vector = matrix peak)
+
+
+def shard(n, world, rank):
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def canonical_weights():
+    from scipy.stats import truncnorm
+    rs = np.random.RandomState(1234)
+    parts = []
+    for fi, fo in zip(LAYERS[:-1], LAYERS[1:]):
+        sigma = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
+        parts.append((truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel())
+        parts.append(np.zeros(fo))
+    return np.concatenate(parts)
+
+
+def make_engine(dtype, device, X_f, X_u, u, lb, ub, world, rank, n_f_total, n_u_total):
+    import pinn_native
+    eng = pinn_native.Engine(LAYERS, lb, ub, pde="burgers", dtype=dtype, device=device)
+    f0, f1 = shard(n_f_total, world, rank)
+    u0, u1 = shard(n_u_total, world, rank)
+    eng.set_collocation(X_f[f0:f1], n_total=n_f_total)
+    eng.set_data(X_u[u0:u1], u[u0:u1], n_total=n_u_total)
+    eng.set_pde_params(NU)
+    return eng
+
+
+def cpu_baseline(X_f, X_u, u, lb, ub, w0, budget_s=12.0):
+    """The oracle (numpy f64 port of the reference path) timed on this host: Adam iterations on
+    the same N_f=10000 workload until ~budget_s of CPU time is spent."""
+    from oracle import pde, optim
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    adam = optim.Adam(0.03, 0.9, 0.999, None)
+    w = w0.copy()
+    pde.burgers_loss_grad(w, LAYERS, lb, ub, X_f, X_u, u, NU)          # warm the BLAS threads
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < 400:
+        _, g, _ = pde.burgers_loss_grad(w, LAYERS, lb, ub, X_f, X_u, u, NU)
+        w = adam.step(w, g)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": X_f.shape[0] * n / dt, "unit": "collocation-points/s", "cores": int(threads),
+            "kind": "port",
+            "sample": "%d Adam iterations of oracle/ (numpy float64) on N_f=%d, N_u=%d, 8x20 "
+                      "MLP in %.1f s" % (n, X_f.shape[0], X_u.shape[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--dtype", default=os.environ.get("PINN_BENCH_DTYPE", "f32"), choices=["f32", "f64"])
+    ap.add_argument("--nf-per-gpu", type=int, default=10000)
+    ap.add_argument("--kernel-path", type=int, default=-1, help="-1 engine default, 0 generic, 1 fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-final-error", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
+                     "(--nproc-per-node %d)" % (args.gpus, args.gpus))
+        args.gpus = world
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    import burgersutil
+    import pinn_native
+    n_f_total = args.nf_per_gpu * world
+    np.random.seed(1234)
+    r = burgersutil.prep_data(os.path.join(PKG, "1d-burgers", "data", "burgers_shock.mat"),
+                              100, n_f_total, noise=0.0)
+    X_star, u_star, X_u, u, X_f, ub, lb = r[5], r[6], r[7], r[8], r[9], r[10], r[11]
+    w0 = canonical_weights()
+
+    eng = make_engine(args.dtype, local_rank, X_f, X_u, u, lb, ub, world, rank, n_f_total, 100)
+    if args.kernel_path >= 0:
+        eng.set_kernel_path(args.kernel_path)
+    if world > 1:
+        ids = [pinn_native.Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        eng.comm_init(ids[0], world, rank)
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            dist.barrier()
+        eng.sync()
+
+    k_adam = args.steps // 3
+    k_lbfgs = args.steps - k_adam
+    eng.set_weights(w0)
+    eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+    # ---- warm-up (untimed) ------------------------------------------------------------------
+    if args.warmup > 0:
+        eng.adam_run(args.warmup, want_losses=False)
+    eng.set_weights(w0)
+    eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+    eng.timing_enable(args.steps)
+    # ---- timed region: exactly K optimiser iterations = K loss+grad evaluations ----------------
+    done = 0
+    barrier()
+    t0 = time.perf_counter()
+    if k_adam:
+        eng.adam_run(k_adam, want_losses=False)
+    if k_lbfgs:
+        eng.lbfgs_begin(k_lbfgs, 0.8, 50, float(np.finfo(float).eps))      # initial evaluation
+        done = 0
+        while not done:
+            _, _, done = eng.lbfgs_run(k_lbfgs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tim = eng.timing_read()
+    eng.timing_enable(0)
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+
+    # ---- accuracy leg (untimed): the reference's default schedule, final relative L2 error ----
+    final_err = None
+    if not args.no_final_error:
+        eng.set_weights(w0)
+        eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+        eng.adam_run(100, want_losses=False)
+        eng.lbfgs_begin(200, 0.8, 50, float(np.finfo(float).eps))
+        d2 = 0
+        while not d2:
+            _, _, d2 = eng.lbfgs_run(200)
+        u_pred = eng.predict(X_star)
+        final_err = float(np.linalg.norm(u_star - u_pred, 2) / np.linalg.norm(u_star, 2))
+
+    if rank == 0:
+        n_f_local = shard(n_f_total, world, 0)[1]
+        n_u_local = shard(100, world, 0)[1]
+        flops_per_eval = 24.0 * M_W * n_f_local + 6.0 * M_W * n_u_local    # SURVEY.md 8(d), per rank
+        sweeps_s = tim["sweeps_ms"] * 1e-3
+        achieved = flops_per_eval / sweeps_s / 1e12 if sweeps_s > 0 else None
+        peak = PEAK_TFLOPS[args.dtype]
+        out = {
+            "metric": "collocation-points/sec",
+            "value": n_f_total * args.steps / elapsed,
+            "unit": "collocation-points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "1D Burgers continuous inference (BASELINE configs[1]): 8x20 tanh "
+                                   "MLP, N_u=100, N_f=%d per GPU (LHS, seed 1234), %d Adam + %d L-BFGS "
+                                   "iterations, canonical glorot init" % (args.nf_per_gpu, k_adam, k_lbfgs),
+                       "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world,
+                       "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
+            "final_l2_error": final_err,
+            "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "kernel": "loss+grad sweeps (forward + reverse)",
+                         "avg_launch_ms": tim["sweeps_ms"], "evals_timed": tim["n"],
+                         "algorithmic_flop_per_launch": flops_per_eval,
+                         "eval_ms_incl_reduce_allreduce": tim["eval_ms"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(X_f[:args.nf_per_gpu], X_u, u, lb, ub, w0)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

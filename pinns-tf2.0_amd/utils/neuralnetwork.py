@@ -1,0 +1,252 @@
+"""NeuralNetwork base class with the reference's public surface
+(utils/neuralnetwork.py:7-159 of PINNs-TF2.0) on top of the MI355X HIP engine.
+
+What is kept: constructor `NeuralNetwork(hp, logger, ub, lb)`, the attributes
+`nt_config, tf_epochs, tf_optimizer, dtype, model, sizes_w, sizes_b, logger`, and the methods
+`loss, grad, wrap_training_variables, get_params, get_weights, set_weights,
+get_loss_and_flat_grad, tf_optimization, tf_optimization_step, nt_optimization,
+nt_optimization_steps, fit, predict, summary, tensor` with the same argument meaning and
+return shapes (numpy arrays where the reference returns eager tensors).
+
+What changes: there is no TensorFlow, so a subclass cannot spell its PDE with GradientTapes.
+It names one of the engine's residual kinds instead (`pde="burgers" | "burgers_ide" |
+"schrodinger"`) and the engine evaluates forward, u_t/u_x/u_xx, residual, loss and the flat
+gradient on the GPU (csrc/).  Extra, optional hp keys: "dtype" ("f32" default | "f64") for
+the kernel arithmetic, "device" (HIP ordinal).  Host interchange stays float64.
+
+There is no CPU path: constructing a NeuralNetwork without the HIP library or a GPU raises.
+"""
+import numpy as np
+
+from custom_lbfgs import lbfgs, Struct
+
+import os
+import sys
+sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from pinn_native import Engine  # noqa: E402
+
+
+class _AdamConfig(object):
+    """Holds what tf.keras.optimizers.Adam held (neuralnetwork.py:19-22)."""
+
+    def __init__(self, learning_rate, beta_1, epsilon, beta_2=0.999):
+        self.learning_rate = learning_rate
+        self.beta_1 = beta_1
+        self.beta_2 = beta_2
+        self.epsilon = 1e-7 if epsilon is None else epsilon     # Keras default
+
+
+class _ModelView(object):
+    """Stand-in for the Keras Sequential the reference exposes as `self.model`: callable for
+    a plain forward pass, `.summary()`, `.layers` describing the Dense stack."""
+
+    def __init__(self, owner, layers):
+        self._owner = owner
+        self.layers = [("lambda", "2(X-lb)/(ub-lb)-1")] + [
+            ("dense", fi, fo, "tanh" if i < len(layers) - 2 else "linear")
+            for i, (fi, fo) in enumerate(zip(layers[:-1], layers[1:]))]
+
+    def __call__(self, X):
+        return self._owner._engine.predict(_as_points(X, self._owner))
+
+    def summary(self):
+        rows = ["%-10s %-14s %8s" % ("layer", "shape", "params")]
+        total = 0
+        for l in self.layers[1:]:
+            n = l[1] * l[2] + l[2]
+            total += n
+            rows.append("%-10s %-14s %8d" % ("dense/" + l[3], "[%d,%d]" % (l[1], l[2]), n))
+        rows.append("total trainable scalars: %d" % total)
+        return "\n".join(rows)
+
+
+def _as_points(X, owner):
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    if X.shape[1] == 1:
+        # Schrodinger driver quirk (inf_cont_schrodinger.py:164): x0 of shape [N,1] is handed
+        # to a 2-input network.  Default: the evident intent (x0, t=0); hp["compat_x0_broadcast"]
+        # reproduces what broadcasting against lb/ub does, i.e. (x0, x0).
+        second = X if owner._compat_x0 else np.zeros_like(X)
+        X = np.concatenate([X, second], axis=1)
+    return X
+
+
+class NeuralNetwork(object):
+    pde = "burgers"
+
+    def __init__(self, hp, logger, ub, lb, pde=None):
+        layers = hp["layers"]
+        if pde is not None:
+            self.pde = pde
+
+        # L-BFGS configuration, same fields as the reference (neuralnetwork.py:13-17)
+        self.nt_config = Struct()
+        self.nt_config.learningRate = hp["nt_lr"]
+        self.nt_config.maxIter = hp["nt_epochs"]
+        self.nt_config.nCorrection = hp["nt_ncorr"]
+        self.nt_config.tolFun = 1.0 * np.finfo(float).eps
+        self.tf_epochs = hp["tf_epochs"]
+        self.tf_optimizer = _AdamConfig(hp["tf_lr"], hp["tf_b1"], hp["tf_eps"])
+
+        self.dtype = "float64"                       # host interchange dtype
+        self.compute_dtype = hp.get("dtype", "f32")  # kernel arithmetic
+        self._compat_x0 = bool(hp.get("compat_x0_broadcast", False))
+        self.layers = [int(v) for v in layers]
+        self.ub = np.asarray(ub, dtype=np.float64)
+        self.lb = np.asarray(lb, dtype=np.float64)
+
+        self._engine = Engine(self.layers, self.lb, self.ub, pde=self.pde,
+                              dtype=self.compute_dtype, device=int(hp.get("device", 0)))
+        self.model = _ModelView(self, self.layers)
+
+        # flat-layout bookkeeping, same rule as the reference (all hidden widths = layers[1])
+        self.sizes_w = []
+        self.sizes_b = []
+        for i, width in enumerate(self.layers):
+            if i != 1:
+                self.sizes_w.append(int(width * self.layers[1]))
+                self.sizes_b.append(int(width if i != 0 else self.layers[1]))
+
+        self._engine.set_weights(self._initial_weights(hp))
+        self._engine.adam_init(self.tf_optimizer.learning_rate, self.tf_optimizer.beta_1,
+                               self.tf_optimizer.beta_2, self.tf_optimizer.epsilon)
+        self._bound = None
+        self.logger = logger
+
+    # ---- initialisation ------------------------------------------------------------------------
+    def _n_net(self):
+        return sum(fi * fo + fo for fi, fo in zip(self.layers[:-1], self.layers[1:]))
+
+    def _extra_params(self):
+        """Trainable scalars appended after the network weights (identification: lambdas)."""
+        return np.zeros(0)
+
+    def _initial_weights(self, hp):
+        """glorot_normal kernels + zero biases (neuralnetwork.py:31-37): truncated normal within
+        two sigma, sigma = sqrt(2/(fan_in+fan_out))/0.87962566103423978, drawn per Dense layer
+        from one RandomState(hp.get("seed", 1234)) -- the engine's canonical initial vector."""
+        from scipy.stats import truncnorm
+        rs = np.random.RandomState(int(hp.get("seed", 1234)))
+        chunks = []
+        for fi, fo in zip(self.layers[:-1], self.layers[1:]):
+            sigma = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
+            chunks.append((truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel())
+            chunks.append(np.zeros(fo))
+        chunks.append(self._extra_params())
+        return np.concatenate(chunks)
+
+    # ---- loss / gradient -----------------------------------------------------------------------
+    def loss(self, u, u_pred):
+        """Plain data misfit, as the base class of the reference (neuralnetwork.py:51-52)."""
+        return float(np.mean(np.square(np.asarray(u) - np.asarray(u_pred))))
+
+    def _bind(self, X, u):
+        X = _as_points(X, self)
+        u = np.asarray(u, dtype=np.float64).reshape(X.shape[0], -1)
+        key = (X.shape, u.shape, X.tobytes(), u.tobytes()) if X.shape[0] <= 4096 else \
+            (X.shape, u.shape, float(X.sum()), float(u.sum()), X[:4].tobytes(), X[-4:].tobytes())
+        if key != self._bound:
+            self._engine.set_data(X, u)
+            self._bound = key
+
+    def _split(self, flat):
+        out, off = [], 0
+        for fi, fo in zip(self.layers[:-1], self.layers[1:]):
+            out.append(flat[off:off + fi * fo].reshape(fi, fo).copy())
+            off += fi * fo
+            out.append(flat[off:off + fo].copy())
+            off += fo
+        for v in flat[off:]:
+            out.append(np.array([v]))
+        return out
+
+    def grad(self, X, u):
+        self._bind(X, u)
+        loss_value, flat, _ = self._engine.loss_grad()
+        return loss_value, self._split(flat)
+
+    def wrap_training_variables(self):
+        return self._split(self._engine.get_weights())
+
+    def get_params(self, numpy=False):
+        return []
+
+    def get_weights(self, convert_to_tensor=True):
+        w = self._engine.get_weights()
+        return w if convert_to_tensor else list(w)
+
+    def set_weights(self, w):
+        self._engine.set_weights(np.asarray(w, dtype=np.float64).ravel())
+
+    def get_loss_and_flat_grad(self, X, u):
+        self._bind(X, u)
+
+        def loss_and_flat_grad(w):
+            self.set_weights(w)
+            loss_value, flat, _ = self._engine.loss_grad()
+            return loss_value, flat
+
+        return loss_and_flat_grad
+
+    # ---- Adam ------------------------------------------------------------------------------------
+    def tf_optimization(self, X_u, u):
+        self.logger.log_train_opt("Adam")
+        self._bind(X_u, u)
+        freq = max(int(self.logger.frequency), 1)
+        epoch = 0
+        while epoch < self.tf_epochs:
+            # run up to and including the next epoch that is logged, then sync once
+            stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
+            losses = self._engine.adam_run(stop - epoch)
+            for k, loss_value in enumerate(losses):
+                self.logger.log_train_epoch(epoch + k, loss_value)
+            epoch = stop
+
+    def tf_optimization_step(self, X_u, u):
+        self._bind(X_u, u)
+        return float(self._engine.adam_run(1)[0])
+
+    # ---- L-BFGS ----------------------------------------------------------------------------------
+    def nt_optimization(self, X_u, u):
+        """Device-resident L-BFGS with the semantics of custom_lbfgs.lbfgs as the reference drives
+        it (neuralnetwork.py:118-136): same config Struct, same log callbacks, and the model ends
+        at the last evaluated iterate."""
+        self.logger.log_train_opt("LBFGS")
+        self._bind(X_u, u)
+        cfg = self.nt_config
+        if cfg.maxIter == 0:
+            return
+        self._engine.lbfgs_begin(cfg.maxIter, cfg.learningRate or 1, cfg.nCorrection or 100,
+                                 cfg.tolFun or 1e-5, cfg.tolX or 1e-19, cfg.maxEval or 0.0)
+        freq = max(int(self.logger.frequency), 1)
+        done = 0
+        while not done:
+            iters, losses, done = self._engine.lbfgs_run(freq)
+            for it, loss_value in zip(iters, losses):
+                self.logger.log_train_epoch(int(it), loss_value, "", True)
+
+    def nt_optimization_steps(self, loss_and_flat_grad):
+        """Host-driven variant with the reference's signature: any closure w -> (loss, grad)."""
+        return lbfgs(loss_and_flat_grad, self.get_weights(), self.nt_config, Struct(), True,
+                     lambda epoch, loss, is_iter:
+                     self.logger.log_train_epoch(epoch, loss, "", is_iter))
+
+    # ---- driver ----------------------------------------------------------------------------------
+    def fit(self, X_u, u):
+        self.logger.log_train_start(self)
+        X_u = self.tensor(X_u)
+        u = self.tensor(u)
+        self.tf_optimization(X_u, u)
+        self.nt_optimization(X_u, u)
+        self.logger.log_train_end(self.tf_epochs + self.nt_config.maxIter)
+
+    def predict(self, X_star):
+        return self._engine.predict(_as_points(X_star, self))
+
+    def summary(self):
+        return self.model.summary()
+
+    def tensor(self, X):
+        return np.asarray(X, dtype=np.float64)
