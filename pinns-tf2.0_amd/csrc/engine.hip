@@ -187,8 +187,11 @@ static int ensure_sets(pinn_ctx* c) {
   c->chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
   c->n_rows = c->chunk / 64;
   const size_t W = c->nd.width, H = c->nd.n_hidden;
-  const size_t need_S = H * W * (size_t)c->chunk * 4 * rs, need_Z = W * (size_t)c->chunk * 4 * rs;
-  const size_t need_part = (size_t)c->n_rows * c->R * rs;
+  // the fused kernel keeps the whole set's stash (one launch); the generic path works in chunks
+  const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
+  const size_t rows = c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
+  const size_t need_S = H * W * stash_pts * 4 * rs, need_Z = W * (size_t)c->chunk * 4 * rs;
+  const size_t need_part = rows * c->R * rs;
   if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
   if (need_Z > c->cap_Z) {
     if (dev_alloc(&c->ZA, need_Z)) return PINN_EHIP;
@@ -214,7 +217,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4) {
   if (c->path == 1) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
                                              (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
-                                             st, (real)c->nu, (real*)c->part, c->R, c->stream);
+                                             st, (real)c->nu, (vec4<real>*)c->S, (real*)c->part, c->R,
+                                             c->stream);
     if (rc) return fail(PINN_EHIP, "fused20 launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
   } else {

@@ -1,17 +1,309 @@
-// kernels_fused20.h -- fused width-20 Burgers loss+gradient kernel (placeholder until the
-// LDS/MFMA kernel lands; reports "unsupported" so the generic kernels serve every shape).
+// kernels_fused20.h -- fused loss+gradient kernel for width-20 tanh MLPs (the Burgers nets of
+// 1d-burgers/inf_cont_burgers.py:33 and ide_cont_burgers.py:33), one launch per evaluation.
+//
+// Mapping (wave64, gfx950):
+//   workgroup = 256 threads = 4 waves = one tile of 64 points; lane = point, wave w owns the
+//   5 features [5w, 5w+5) of every hidden layer (one wave per SIMD of the CU).
+//   * layer GEMVs (forward z = in.W, reverse in_bar = z_bar.W^T): each wave needs all 20 input
+//     features of its 64 points -> exchanged through LDS as [feature][point] float4 (h,p,q,r)
+//     tiles (ds_read_b128, conflict-free), weights are wave-uniform and come through the scalar
+//     cache, so the 2x400 FMAs per layer are VGPR x SGPR with no operand traffic.
+//   * weight gradient dW = IN^T . ZBAR is a [21 x 256] x [256 x 20] contraction over the tile's
+//     (point,channel) rows: it runs on the matrix pipe as four 16x16 output tiles (one per wave)
+//     of v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 reading A and B straight from the same
+//     LDS exchange tiles (row stride padded so the b128 operand fetches are conflict-free).  A
+//     constant "ones" feature row turns the bias gradient into row 20 of the same product.  No
+//     cross-lane shuffles, no atomics; f32 MFMA is bit-equal to an fmaf chain, so the result is
+//     deterministic.
+//   * per-layer Taylor channels (a, z_x, z_t, z_xx) of the wave's own 5 features are stashed to
+//     HBM/L2 in [layer][feature][point] order (1 KiB contiguous per wave store) and read back by
+//     the same lanes in the reverse sweep.
+//   * each workgroup emits one partial-gradient row; k_reduce_rows sums rows in fixed order.
+//
+// Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
+// the outer tape of utils/neuralnetwork.py:55-59.
 #pragma once
 #include "kernels_generic.h"
 
 namespace pinn {
 
-inline bool fused20_supported(const NetDesc&) { return false; }
-inline int fused20_rows(const SetDesc&) { return 0; }
+constexpr int FW = 20;          // hidden width served by this kernel
+constexpr int FF = 5;           // features per wave
+constexpr int FROWS = 21;       // 20 features + the ones row (bias gradient)
+
+template <typename real> struct FusedTraits;
+template <> struct FusedTraits<float> {
+  using acc_t = float __attribute__((ext_vector_type(4)));
+  static constexpr int RS4 = 65;     // LDS row stride in vec4 units (64 points + 1 pad): 1040 B
+  static constexpr int NBUF = 2;     // ping-pong (IN, ZBAR) pairs -> one barrier per layer
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+};
+template <> struct FusedTraits<double> {
+  using acc_t = double __attribute__((ext_vector_type(4)));
+  static constexpr int RS4 = 65;     // 65 * 32 B = 2080 B
+  static constexpr int NBUF = 1;     // 160 KiB LDS holds one pair in f64 -> two barriers per layer
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+};
+
+inline bool fused20_supported(const NetDesc& nd) {
+  return nd.width == FW && nd.n_out == 1 && nd.n_hidden >= 2;
+}
+inline int fused20_rows(const SetDesc& sd) { return sd.n_pad / 64; }
+template <typename real>
+inline size_t fused20_lds_bytes() {
+  return (size_t)2 * FusedTraits<real>::NBUF * FROWS * FusedTraits<real>::RS4 * sizeof(vec4<real>);
+}
 
 template <typename real, int PDE>
-inline int fused20_launch(const NetDesc&, const SetDesc&, const real*, const real*, const real*,
-                          const real*, real, real, real, real, real, real*, int, hipStream_t) {
-  return (int)hipErrorNotSupported;
+__global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
+                                                 const real* __restrict__ th,
+                                                 const real* __restrict__ xs,
+                                                 const real* __restrict__ ts,
+                                                 const real* __restrict__ tgt, real lbx, real lbt,
+                                                 real sx, real st, real nu,
+                                                 vec4<real>* __restrict__ S,
+                                                 real* __restrict__ part, int R) {
+  using TR = FusedTraits<real>;
+  using acc_t = typename TR::acc_t;
+  constexpr int RS4 = TR::RS4;
+  constexpr int BUFV = FROWS * RS4;               // vec4 elements per LDS buffer
+  extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
+  vec4<real>* const lds = reinterpret_cast<vec4<real>*>(lds_raw);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j0 = wave * FF;
+  const int pt = blockIdx.x * 64 + lane;
+  const int n_pad = sd.n_pad;
+  const int H = nd.n_hidden;
+  real* __restrict__ row = part + (size_t)blockIdx.x * R;
+
+  auto BUF = [&](int b) { return lds + b * BUFV; };
+
+  // ones row (feature 20 of every IN buffer): (1,0,0,0) per point -> bias gradients via MFMA
+  if (wave == 0) {
+#pragma unroll
+    for (int b = 0; b < 2 * TR::NBUF; b += 2) BUF(b)[FW * RS4 + lane] = vec4<real>{1, 0, 0, 0};
+  }
+
+  const real x = xs[pt], t = ts[pt];
+  const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
+
+  // ------------------------------------------------------------------ forward
+  vec4<real> cur_s[FF];                   // stash entries of the current layer, own features
+  {  // dense 0
+    const real* __restrict__ W0 = th + nd.off_w[0];
+    const real* __restrict__ b0 = th + nd.off_b[0];
+    vec4<real>* __restrict__ X = BUF(0);
+#pragma unroll
+    for (int jj = 0; jj < FF; ++jj) {
+      const int j = j0 + jj;
+      const real w0 = W0[j], w1 = W0[FW + j];
+      const real z = hx * w0 + ht * w1 + b0[j];
+      const vec4<real> s{tanh_r(z), sx * w0, st * w1, real(0)};
+      cur_s[jj] = s;
+      S[(size_t)j * n_pad + pt] = s;
+      real d1, d2;
+      X[j * RS4 + lane] = channels_of(s, d1, d2);
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int d = 1; d < H; ++d) {
+    const real* __restrict__ Wd = th + nd.off_w[d];
+    const real* __restrict__ bd = th + nd.off_b[d];
+    const vec4<real>* __restrict__ Xin = BUF(cur);
+    vec4<real>* __restrict__ Xout = BUF(cur ^ 1);
+    real az[FF], ap[FF], aq[FF], ar[FF];
+#pragma unroll
+    for (int jj = 0; jj < FF; ++jj) { az[jj] = bd[j0 + jj]; ap[jj] = aq[jj] = ar[jj] = real(0); }
+#pragma unroll
+    for (int k = 0; k < FW; ++k) {
+      const vec4<real> in = Xin[k * RS4 + lane];
+#pragma unroll
+      for (int jj = 0; jj < FF; ++jj) {
+        const real w = Wd[k * FW + j0 + jj];
+        az[jj] += in.x * w; ap[jj] += in.y * w; aq[jj] += in.z * w; ar[jj] += in.w * w;
+      }
+    }
+    vec4<real>* __restrict__ Sd = S + (size_t)d * FW * n_pad + pt;
+#pragma unroll
+    for (int jj = 0; jj < FF; ++jj) {
+      const vec4<real> s{tanh_r(az[jj]), ap[jj], aq[jj], ar[jj]};
+      cur_s[jj] = s;
+      Sd[(size_t)(j0 + jj) * n_pad] = s;
+      real d1, d2;
+      Xout[(j0 + jj) * RS4 + lane] = channels_of(s, d1, d2);
+    }
+    cur ^= 1;
+    __syncthreads();
+  }
+  // linear output layer (every wave computes it: 80 FMAs) -> o = (u, u_x, u_t, u_xx)
+  vec4<real> o{th[nd.off_b[H]], 0, 0, 0};
+  {
+    const real* __restrict__ WL = th + nd.off_w[H];
+    const vec4<real>* __restrict__ Xin = BUF(cur);
+#pragma unroll
+    for (int k = 0; k < FW; ++k) {
+      const vec4<real> in = Xin[k * RS4 + lane];
+      const real w = WL[k];
+      o.x += in.x * w; o.y += in.y * w; o.z += in.z * w; o.w += in.w * w;
+    }
+  }
+
+  // ------------------------------------------------------------------ seeds + loss parts
+  real c1 = real(1), c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp(th[nd.n_net + 1]); }
+  vec4<real> sb{0, 0, 0, 0};
+  {
+    real lt0 = 0, lt1 = 0, dl0 = 0, dl1 = 0;
+    const int cls = point_class(sd, pt);
+    const real inv_nf = (real)sd.inv_nf, inv_nu = (real)sd.inv_nu;
+    const bool res = (PDE == 0) ? (cls == CLS_COL) : (cls == CLS_DATA);
+    if (res) {
+      const real wgt = (PDE == 0) ? inv_nf : inv_nu;
+      const real f = o.z + c1 * o.x * o.y - c2 * o.w;
+      const real fb = real(2) * f * wgt;
+      lt0 = f * f * wgt;
+      sb = vec4<real>{fb * c1 * o.y, fb * c1 * o.x, fb, -c2 * fb};
+      if (PDE == 1) { dl0 = fb * o.x * o.y; dl1 = -fb * c2 * o.w; }
+    }
+    if (cls == CLS_DATA) {
+      const real dd = o.x - tgt[pt];
+      lt1 = dd * dd * inv_nu;
+      sb.x += real(2) * dd * inv_nu;
+    }
+    if (wave == 0) {
+      const real a = wave_sum(lt0), b = wave_sum(lt1);
+      if (lane == 0) { row[nd.n_theta + 0] = a; row[nd.n_theta + 1] = b; row[nd.n_theta + 2] = real(0); }
+      if (PDE == 1) {
+        const real g1 = wave_sum(dl0), g2 = wave_sum(dl1);
+        if (lane == 0) { row[nd.n_net] = g1; row[nd.n_net + 1] = g2; }
+      }
+    }
+  }
+
+  // ------------------------------------------------------------------ reverse sweep
+  vec4<real> ob[FF];                       // adjoint of the outputs of the layer below, own features
+  {  // dense H (linear): z_bar = sb
+    const real* __restrict__ WL = th + nd.off_w[H];
+    real keep = 0;
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) {
+      real d1, d2;
+      const vec4<real> in = channels_of(cur_s[kk], d1, d2);
+      const real g = wave_sum(dot4(in, sb));
+      if (lane == kk) keep = g;
+      const real w = WL[j0 + kk];
+      ob[kk] = vec4<real>{sb.x * w, sb.y * w, sb.z * w, sb.w * w};
+    }
+    if (lane < FF) row[nd.off_w[H] + j0 + lane] = keep;
+    if (wave == 0) {
+      const real g = wave_sum(sb.x);
+      if (lane == 0) row[nd.off_b[H]] = g;
+    }
+  }
+  __syncthreads();        // every wave is done reading the forward tile before it is overwritten
+
+  const int ti = wave >> 1, tj = wave & 1;                    // this wave's 16x16 tile of dW
+  const int fa = min(16 * ti + (lane & 15), FW);              // A row: input feature (20 = ones)
+  const int fb = min(16 * tj + (lane & 15), FW - 1);          // B column: output feature
+  const int kq = (lane >> 4) * 16;                            // this lane group's 16 points
+  int pair = 0;
+  for (int d = H - 1; d >= 1; --d) {
+    vec4<real>* __restrict__ IN = BUF(2 * pair);
+    vec4<real>* __restrict__ ZB = BUF(2 * pair + 1);
+    const vec4<real>* __restrict__ Sp = S + (size_t)(d - 1) * FW * n_pad + pt;
+    vec4<real> prev_s[FF];
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) prev_s[kk] = Sp[(size_t)(j0 + kk) * n_pad];
+    // phase A: publish own z_bar (layer d) and own layer-(d-1) output channels
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) {
+      ZB[(j0 + kk) * RS4 + lane] = preact_adjoint(cur_s[kk], ob[kk]);
+      real d1, d2;
+      IN[(j0 + kk) * RS4 + lane] = channels_of(prev_s[kk], d1, d2);
+    }
+    __syncthreads();
+    // phase B (matrix pipe): dW_d tile = IN^T . ZB over the 256 (point,channel) rows
+    acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const vec4<real> a4 = IN[fa * RS4 + kq + s];
+      const vec4<real> b4 = ZB[fb * RS4 + kq + s];
+      acc = TR::mfma(a4.x, b4.x, acc);
+      acc = TR::mfma(a4.y, b4.y, acc);
+      acc = TR::mfma(a4.z, b4.z, acc);
+      acc = TR::mfma(a4.w, b4.w, acc);
+    }
+    // phase B (vector pipe): adjoint of own layer-(d-1) outputs = sum_j z_bar_j W_d[k][j]
+    const real* __restrict__ Wd = th + nd.off_w[d];
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) ob[kk] = vec4<real>{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < FW; ++j) {
+      const vec4<real> z4 = ZB[j * RS4 + lane];
+#pragma unroll
+      for (int kk = 0; kk < FF; ++kk) {
+        const real w = Wd[(j0 + kk) * FW + j];
+        ob[kk].x += z4.x * w; ob[kk].y += z4.y * w; ob[kk].z += z4.z * w; ob[kk].w += z4.w * w;
+      }
+    }
+    {  // scatter the dW / db tile into this workgroup's partial row
+      const int jg = 16 * tj + (lane & 15);
+      if (jg < FW) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ig = 16 * ti + TR::out_row(lane, r);
+          if (ig < FW) row[nd.off_w[d] + ig * FW + jg] = acc[r];
+          else if (ig == FW) row[nd.off_b[d] + jg] = acc[r];
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) cur_s[kk] = prev_s[kk];
+    if (TR::NBUF == 2) pair ^= 1; else __syncthreads();
+  }
+  {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
+    real kx = 0, kt = 0, kb = 0;
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) {
+      const vec4<real> zb = preact_adjoint(cur_s[kk], ob[kk]);
+      const real gx = wave_sum(hx * zb.x + sx * zb.y);
+      const real gt = wave_sum(ht * zb.x + st * zb.z);
+      const real gb = wave_sum(zb.x);
+      if (lane == kk) { kx = gx; kt = gt; kb = gb; }
+    }
+    if (lane < FF) {
+      row[nd.off_w[0] + j0 + lane] = kx;
+      row[nd.off_w[0] + FW + j0 + lane] = kt;
+      row[nd.off_b[0] + j0 + lane] = kb;
+    }
+  }
+}
+
+// returns a hipError_t (0 = ok)
+template <typename real, int PDE>
+inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, const real* xs,
+                          const real* ts, const real* tgt, real lbx, real lbt, real sx, real st,
+                          real nu, vec4<real>* S, real* part, int R, hipStream_t stream) {
+  const size_t lds = fused20_lds_bytes<real>();
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused20<real, PDE>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
+                     xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R);
+  return (int)hipGetLastError();
 }
 
 }  // namespace pinn
