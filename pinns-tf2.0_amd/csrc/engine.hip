@@ -1,6 +1,7 @@
 // engine.hip -- context, device memory, launch sequencing and the C ABI (include/pinn_hip.h)
 // of the MI355X PINN engine.  Built for gfx950 only:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC engine.hip -o libpinn_hip.so -lrccl
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC engine.hip \
+//         -o libpinn_hip.so -lrccl
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -117,6 +118,14 @@ struct pinn_ctx {
 };
 
 static size_t real_size(const pinn_ctx* c) { return c->dtype == PINN_F64 ? 8 : 4; }
+
+// the fused kernel serves width-20 Burgers nets whose staged weights fit the 160 KiB LDS
+static bool fused_ok(const pinn_ctx* c) {
+  if (!fused20_supported(c->nd) || c->pde == PINN_PDE_SCHRODINGER) return false;
+  const size_t lds = c->dtype == PINN_F64 ? fused20_lds_bytes<double>(c->nd.n_hidden)
+                                          : fused20_lds_bytes<float>(c->nd.n_hidden);
+  return lds <= 160 * 1024;
+}
 
 template <typename T>
 static int dev_alloc(T** p, size_t bytes) {
@@ -342,7 +351,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   HIPCHK(hipMemsetAsync(c->gl, 0, (size_t)c->R * 8, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   // width-20 Burgers nets take the fused path by default
-  c->path = (fused20_supported(nd) && pde_kind != PINN_PDE_SCHRODINGER) ? 1 : 0;
+  c->path = fused_ok(c) ? 1 : 0;
   *out = c;
   return 0;
 }
@@ -697,8 +706,7 @@ int pinn_sync(pinn_ctx* c) {
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
   REQUIRE(c && (path == 0 || path == 1), "path must be 0 (generic) or 1 (fused width-20)");
   if (path == 1)
-    REQUIRE(fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER,
-            "the fused path needs hidden width 20 and a Burgers problem");
+    REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");
   c->path = path;
   c->sets_dirty = true;
   return 0;

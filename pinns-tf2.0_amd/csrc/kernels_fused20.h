@@ -4,20 +4,24 @@
 // Mapping (wave64, gfx950):
 //   workgroup = 256 threads = 4 waves = one tile of 64 points; lane = point, wave w owns the
 //   5 features [5w, 5w+5) of every hidden layer (one wave per SIMD of the CU).
+//   * hidden-layer weights are staged once per workgroup into LDS in two per-wave packed layouts
+//     (forward columns / reverse rows); a wave fetches the 5 weights it needs per step with one
+//     broadcast ds_read_b128 (+b32), so the FMAs are VGPR x VGPR and nothing competes for SGPRs.
 //   * layer GEMVs (forward z = in.W, reverse in_bar = z_bar.W^T): each wave needs all 20 input
 //     features of its 64 points -> exchanged through LDS as [feature][point] float4 (h,p,q,r)
-//     tiles (ds_read_b128, conflict-free), weights are wave-uniform and come through the scalar
-//     cache, so the 2x400 FMAs per layer are VGPR x SGPR with no operand traffic.
+//     tiles (ds_read_b128, conflict-free); 20 independent accumulators per step give the ILP a
+//     single wave per SIMD needs.
 //   * weight gradient dW = IN^T . ZBAR is a [21 x 256] x [256 x 20] contraction over the tile's
 //     (point,channel) rows: it runs on the matrix pipe as four 16x16 output tiles (one per wave)
 //     of v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 reading A and B straight from the same
-//     LDS exchange tiles (row stride padded so the b128 operand fetches are conflict-free).  A
-//     constant "ones" feature row turns the bias gradient into row 20 of the same product.  No
-//     cross-lane shuffles, no atomics; f32 MFMA is bit-equal to an fmaf chain, so the result is
-//     deterministic.
+//     LDS exchange tiles (row stride padded so the b128 operand fetches are conflict-free),
+//     interleaved with the reverse GEMV's vector FMAs.  A constant "ones" feature row turns the
+//     bias gradient into row 20 of the same product.  No cross-lane shuffles, no atomics; f32
+//     MFMA is bit-equal to an fmaf chain, so the result is deterministic.
 //   * per-layer Taylor channels (a, z_x, z_t, z_xx) of the wave's own 5 features are stashed to
 //     HBM/L2 in [layer][feature][point] order (1 KiB contiguous per wave store) and read back by
-//     the same lanes in the reverse sweep.
+//     the same lanes in the reverse sweep, prefetched one layer ahead; workgroup barriers wait on
+//     LDS traffic only, never on those stores.
 //   * each workgroup emits one partial-gradient row; k_reduce_rows sums rows in fixed order.
 //
 // Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
@@ -36,6 +40,11 @@ template <> struct FusedTraits<float> {
   using acc_t = float __attribute__((ext_vector_type(4)));
   static constexpr int RS4 = 65;     // LDS row stride in vec4 units (64 points + 1 pad): 1040 B
   static constexpr int NBUF = 2;     // ping-pong (IN, ZBAR) pairs -> one barrier per layer
+  static constexpr int WS = 8;       // packed-weight slot: 5 weights + 3 pad = 32 B
+  static __device__ __forceinline__ void load5(const float* p, float w[5]) {
+    const vec4<float> a = *reinterpret_cast<const vec4<float>*>(p);
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = p[4];
+  }
   static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
@@ -45,6 +54,12 @@ template <> struct FusedTraits<double> {
   using acc_t = double __attribute__((ext_vector_type(4)));
   static constexpr int RS4 = 65;     // 65 * 32 B = 2080 B
   static constexpr int NBUF = 1;     // 160 KiB LDS holds one pair in f64 -> two barriers per layer
+  static constexpr int WS = 6;       // 5 weights + 1 pad = 48 B
+  static __device__ __forceinline__ void load5(const double* p, double w[5]) {
+    struct alignas(16) d2 { double a, b; };
+    const d2 u = *reinterpret_cast<const d2*>(p), v = *reinterpret_cast<const d2*>(p + 2);
+    w[0] = u.a; w[1] = u.b; w[2] = v.a; w[3] = v.b; w[4] = p[4];
+  }
   static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
@@ -55,9 +70,35 @@ inline bool fused20_supported(const NetDesc& nd) {
   return nd.width == FW && nd.n_out == 1 && nd.n_hidden >= 2;
 }
 inline int fused20_rows(const SetDesc& sd) { return sd.n_pad / 64; }
+
+// LDS carve-up (units of `real`):
+//   [exchange buffers: 2*NBUF x FROWS x RS4 vec4] [Pf: (H-1) x 20 x 4 x WS] [Pb: same] [bh: (H-1) x 20]
+//   Pf[d][k][w][jj] = W_d[k][5w+jj]   (forward:  wave w's 5 columns of input row k)
+//   Pb[d][j][w][kk] = W_d[5w+kk][j]   (reverse:  wave w's 5 rows at output column j)
 template <typename real>
-inline size_t fused20_lds_bytes() {
-  return (size_t)2 * FusedTraits<real>::NBUF * FROWS * FusedTraits<real>::RS4 * sizeof(vec4<real>);
+inline size_t fused20_lds_bytes(int n_hidden) {
+  using TR = FusedTraits<real>;
+  const size_t xch = (size_t)2 * TR::NBUF * FROWS * TR::RS4 * 4;
+  const size_t wts = (size_t)(n_hidden - 1) * (2 * FW * 4 * TR::WS + FW);
+  return (xch + wts) * sizeof(real);
+}
+
+// LDS-only workgroup barrier: orders this wave's ds ops before the barrier without waiting for
+// outstanding global stores (the stash is only ever re-read by the thread that wrote it).
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// branch-free tanh: sign(x) * (1 - e^{-2|x|}) / (1 + e^{-2|x|}).  Absolute error ~1 ulp of 1.0,
+// the same order as the roundoff already carried by the 20-term pre-activation sums.
+__device__ __forceinline__ float tanh_bf(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.8853900817779268f);
+  const float r = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ double tanh_bf(double x) {
+  const double t = exp(-2.0 * fabs(x));
+  return copysign((1.0 - t) / (1.0 + t), x);
 }
 
 template <typename real, int PDE>
@@ -72,12 +113,14 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
   using TR = FusedTraits<real>;
   using acc_t = typename TR::acc_t;
   constexpr int RS4 = TR::RS4;
-  constexpr int BUFV = FROWS * RS4;               // vec4 elements per LDS buffer
+  constexpr int WS = TR::WS;
+  constexpr int BUFV = FROWS * RS4;               // vec4 elements per exchange buffer
   extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
   vec4<real>* const lds = reinterpret_cast<vec4<real>*>(lds_raw);
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j0 = wave * FF;
   const int pt = blockIdx.x * 64 + lane;
   const int n_pad = sd.n_pad;
@@ -85,7 +128,22 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
   real* __restrict__ row = part + (size_t)blockIdx.x * R;
 
   auto BUF = [&](int b) { return lds + b * BUFV; };
+  real* const Pf = reinterpret_cast<real*>(lds + 2 * TR::NBUF * BUFV);
+  real* const Pb = Pf + (H - 1) * FW * 4 * WS;
+  real* const bh = Pb + (H - 1) * FW * 4 * WS;
 
+  // ---- stage the hidden-layer weights into LDS in the two per-wave packed layouts
+  for (int idx = tid; idx < (H - 1) * FW * FW; idx += 256) {
+    const int d1 = idx / (FW * FW), rem = idx - d1 * FW * FW;
+    const int k = rem / FW, j = rem - k * FW;
+    const real w = th[nd.off_w[d1 + 1] + rem];
+    Pf[((d1 * FW + k) * 4 + j / FF) * WS + j % FF] = w;
+    Pb[((d1 * FW + j) * 4 + k / FF) * WS + k % FF] = w;
+  }
+  for (int idx = tid; idx < (H - 1) * FW; idx += 256) {
+    const int d1 = idx / FW;
+    bh[idx] = th[nd.off_b[d1 + 1] + idx - d1 * FW];
+  }
   // ones row (feature 20 of every IN buffer): (1,0,0,0) per point -> bias gradients via MFMA
   if (wave == 0) {
 #pragma unroll
@@ -106,43 +164,46 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
       const int j = j0 + jj;
       const real w0 = W0[j], w1 = W0[FW + j];
       const real z = hx * w0 + ht * w1 + b0[j];
-      const vec4<real> s{tanh_r(z), sx * w0, st * w1, real(0)};
+      const vec4<real> s{tanh_bf(z), sx * w0, st * w1, real(0)};
       cur_s[jj] = s;
       S[(size_t)j * n_pad + pt] = s;
       real d1, d2;
       X[j * RS4 + lane] = channels_of(s, d1, d2);
     }
   }
-  __syncthreads();
+  __syncthreads();                        // weights staged + layer-0 tile published
   int cur = 0;
   for (int d = 1; d < H; ++d) {
-    const real* __restrict__ Wd = th + nd.off_w[d];
-    const real* __restrict__ bd = th + nd.off_b[d];
     const vec4<real>* __restrict__ Xin = BUF(cur);
     vec4<real>* __restrict__ Xout = BUF(cur ^ 1);
+    const real* __restrict__ Wf = Pf + ((d - 1) * FW * 4 + wave) * WS;
     real az[FF], ap[FF], aq[FF], ar[FF];
 #pragma unroll
-    for (int jj = 0; jj < FF; ++jj) { az[jj] = bd[j0 + jj]; ap[jj] = aq[jj] = ar[jj] = real(0); }
+    for (int jj = 0; jj < FF; ++jj) {
+      az[jj] = bh[(d - 1) * FW + j0 + jj];
+      ap[jj] = aq[jj] = ar[jj] = real(0);
+    }
 #pragma unroll
     for (int k = 0; k < FW; ++k) {
       const vec4<real> in = Xin[k * RS4 + lane];
+      real w[FF];
+      TR::load5(Wf + k * 4 * WS, w);
 #pragma unroll
       for (int jj = 0; jj < FF; ++jj) {
-        const real w = Wd[k * FW + j0 + jj];
-        az[jj] += in.x * w; ap[jj] += in.y * w; aq[jj] += in.z * w; ar[jj] += in.w * w;
+        az[jj] += in.x * w[jj]; ap[jj] += in.y * w[jj]; aq[jj] += in.z * w[jj]; ar[jj] += in.w * w[jj];
       }
     }
     vec4<real>* __restrict__ Sd = S + (size_t)d * FW * n_pad + pt;
 #pragma unroll
     for (int jj = 0; jj < FF; ++jj) {
-      const vec4<real> s{tanh_r(az[jj]), ap[jj], aq[jj], ar[jj]};
+      const vec4<real> s{tanh_bf(az[jj]), ap[jj], aq[jj], ar[jj]};
       cur_s[jj] = s;
       Sd[(size_t)(j0 + jj) * n_pad] = s;
       real d1, d2;
       Xout[(j0 + jj) * RS4 + lane] = channels_of(s, d1, d2);
     }
     cur ^= 1;
-    __syncthreads();
+    lds_barrier();
   }
   // linear output layer (every wave computes it: 80 FMAs) -> o = (u, u_x, u_t, u_xx)
   vec4<real> o{th[nd.off_b[H]], 0, 0, 0};
@@ -191,6 +252,12 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
 
   // ------------------------------------------------------------------ reverse sweep
   vec4<real> ob[FF];                       // adjoint of the outputs of the layer below, own features
+  vec4<real> prev_s[FF];                   // stash of layer d-1 (prefetched one layer ahead)
+  {
+    const vec4<real>* __restrict__ Sp = S + (size_t)(H - 2) * FW * n_pad + pt;
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) prev_s[kk] = Sp[(size_t)(j0 + kk) * n_pad];
+  }
   {  // dense H (linear): z_bar = sb
     const real* __restrict__ WL = th + nd.off_w[H];
     real keep = 0;
@@ -209,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
       if (lane == 0) row[nd.off_b[H]] = g;
     }
   }
-  __syncthreads();        // every wave is done reading the forward tile before it is overwritten
+  lds_barrier();          // every wave is done reading the forward tile before it is overwritten
 
   const int ti = wave >> 1, tj = wave & 1;                    // this wave's 16x16 tile of dW
   const int fa = min(16 * ti + (lane & 15), FW);              // A row: input feature (20 = ones)
@@ -219,10 +286,13 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
   for (int d = H - 1; d >= 1; --d) {
     vec4<real>* __restrict__ IN = BUF(2 * pair);
     vec4<real>* __restrict__ ZB = BUF(2 * pair + 1);
-    const vec4<real>* __restrict__ Sp = S + (size_t)(d - 1) * FW * n_pad + pt;
-    vec4<real> prev_s[FF];
+    vec4<real> next_s[FF];
+    {
+      const int dn = d >= 2 ? d - 2 : 0;                      // (d == 1: harmless re-read)
+      const vec4<real>* __restrict__ Sp = S + (size_t)dn * FW * n_pad + pt;
 #pragma unroll
-    for (int kk = 0; kk < FF; ++kk) prev_s[kk] = Sp[(size_t)(j0 + kk) * n_pad];
+      for (int kk = 0; kk < FF; ++kk) next_s[kk] = Sp[(size_t)(j0 + kk) * n_pad];
+    }
     // phase A: publish own z_bar (layer d) and own layer-(d-1) output channels
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) {
@@ -230,29 +300,30 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
       real d1, d2;
       IN[(j0 + kk) * RS4 + lane] = channels_of(prev_s[kk], d1, d2);
     }
-    __syncthreads();
-    // phase B (matrix pipe): dW_d tile = IN^T . ZB over the 256 (point,channel) rows
+    lds_barrier();
+    // phase B: matrix pipe -- dW_d tile = IN^T . ZB over the 256 (point,channel) rows;
+    //          vector pipe -- adjoint of own layer-(d-1) outputs = sum_j z_bar_j W_d[k][j]
+    const real* __restrict__ Wb = Pb + ((d - 1) * FW * 4 + wave) * WS;
     acc_t acc = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const vec4<real> a4 = IN[fa * RS4 + kq + s];
-      const vec4<real> b4 = ZB[fb * RS4 + kq + s];
-      acc = TR::mfma(a4.x, b4.x, acc);
-      acc = TR::mfma(a4.y, b4.y, acc);
-      acc = TR::mfma(a4.z, b4.z, acc);
-      acc = TR::mfma(a4.w, b4.w, acc);
-    }
-    // phase B (vector pipe): adjoint of own layer-(d-1) outputs = sum_j z_bar_j W_d[k][j]
-    const real* __restrict__ Wd = th + nd.off_w[d];
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) ob[kk] = vec4<real>{0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < FW; ++j) {
+      if (j < 16) {
+        const vec4<real> a4 = IN[fa * RS4 + kq + j];
+        const vec4<real> b4 = ZB[fb * RS4 + kq + j];
+        acc = TR::mfma(a4.x, b4.x, acc);
+        acc = TR::mfma(a4.y, b4.y, acc);
+        acc = TR::mfma(a4.z, b4.z, acc);
+        acc = TR::mfma(a4.w, b4.w, acc);
+      }
       const vec4<real> z4 = ZB[j * RS4 + lane];
+      real w[FF];
+      TR::load5(Wb + j * 4 * WS, w);
 #pragma unroll
       for (int kk = 0; kk < FF; ++kk) {
-        const real w = Wd[(j0 + kk) * FW + j];
-        ob[kk].x += z4.x * w; ob[kk].y += z4.y * w; ob[kk].z += z4.z * w; ob[kk].w += z4.w * w;
+        ob[kk].x += z4.x * w[kk]; ob[kk].y += z4.y * w[kk];
+        ob[kk].z += z4.z * w[kk]; ob[kk].w += z4.w * w[kk];
       }
     }
     {  // scatter the dW / db tile into this workgroup's partial row
@@ -267,8 +338,8 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < FF; ++kk) cur_s[kk] = prev_s[kk];
-    if (TR::NBUF == 2) pair ^= 1; else __syncthreads();
+    for (int kk = 0; kk < FF; ++kk) { cur_s[kk] = prev_s[kk]; prev_s[kk] = next_s[kk]; }
+    if (TR::NBUF == 2) pair ^= 1; else lds_barrier();
   }
   {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
     real kx = 0, kt = 0, kb = 0;
@@ -293,13 +364,13 @@ template <typename real, int PDE>
 inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, const real* xs,
                           const real* ts, const real* tgt, real lbx, real lbt, real sx, real st,
                           real nu, vec4<real>* S, real* part, int R, hipStream_t stream) {
-  const size_t lds = fused20_lds_bytes<real>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  const size_t lds = fused20_lds_bytes<real>(nd.n_hidden);
+  static size_t attr_set = 0;
+  if (attr_set < lds) {
     hipError_t e = hipFuncSetAttribute((const void*)k_fused20<real, PDE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set = lds;
   }
   hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
                      xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R);

@@ -15,7 +15,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
-LIB_PATH = os.path.join(_HERE, "libpinn_hip.so")
+LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
 SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
            os.path.join(_CSRC, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
