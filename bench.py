@@ -39,9 +39,8 @@ PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}                          # MI355X_MICR
 
 
 def shard(n, world, rank):
-    base, rem = divmod(n, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    from pinn_native.parallel import shard_bounds
+    return shard_bounds(n, world, rank)
 
 
 def canonical_weights():
@@ -58,10 +57,8 @@ def canonical_weights():
 def make_engine(dtype, device, X_f, X_u, u, lb, ub, world, rank, n_f_total, n_u_total):
     import pinn_native
     eng = pinn_native.Engine(LAYERS, lb, ub, pde="burgers", dtype=dtype, device=device)
-    f0, f1 = shard(n_f_total, world, rank)
-    u0, u1 = shard(n_u_total, world, rank)
-    eng.set_collocation(X_f[f0:f1], n_total=n_f_total)
-    eng.set_data(X_u[u0:u1], u[u0:u1], n_total=n_u_total)
+    from pinn_native.parallel import attach_shards
+    attach_shards(eng, world, rank, X_f=X_f, X_u=X_u, u=u)
     eng.set_pde_params(NU)
     return eng
 
@@ -129,9 +126,8 @@ def main():
     if args.kernel_path >= 0:
         eng.set_kernel_path(args.kernel_path)
     if world > 1:
-        ids = [pinn_native.Engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        eng.comm_init(ids[0], world, rank)
+        from pinn_native.parallel import init_engine_comm
+        init_engine_comm(eng, dist, world, rank)
 
     def barrier():
         eng.sync()

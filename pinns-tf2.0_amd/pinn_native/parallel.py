@@ -1,0 +1,44 @@
+"""Data-parallel plumbing: one process per GPU, collocation/data/boundary sets sharded in
+contiguous blocks, gradient all-reduce by RCCL inside the engine.
+
+`torch.distributed` (gloo) is used only for rendezvous: shipping the 128-byte RCCL unique id
+from rank 0 and for host-side barriers / timing reductions.  The reference has no
+distributed code at all; this is new.
+"""
+import os
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous block [lo, hi) of rank `rank` when n items are split over `world` ranks;
+    the first n % world ranks get one extra item."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def env_world():
+    return (int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def attach_shards(engine, world, rank, X_f=None, X_u=None, u=None, X_lb=None, X_ub=None):
+    """Give `engine` this rank's block of every point set; mean() denominators stay global so
+    that the per-rank partial sums add up to the single-process loss and gradient."""
+    if X_f is not None:
+        lo, hi = shard_bounds(len(X_f), world, rank)
+        engine.set_collocation(X_f[lo:hi], n_total=len(X_f))
+    if X_u is not None:
+        lo, hi = shard_bounds(len(X_u), world, rank)
+        engine.set_data(X_u[lo:hi], u[lo:hi], n_total=len(X_u))
+    if X_lb is not None:
+        lo, hi = shard_bounds(len(X_lb), world, rank)
+        engine.set_boundary(X_lb[lo:hi], X_ub[lo:hi], n_total=len(X_lb))
+
+
+def init_engine_comm(engine, dist, world, rank):
+    """Create the RCCL communicator of `engine`: rank 0 draws the unique id, torch.distributed
+    (any backend; gloo in this repo) broadcasts it, every rank joins."""
+    from . import Engine
+    box = [Engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    engine.comm_init(box[0], world, rank)

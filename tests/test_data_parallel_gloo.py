@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the data-parallel contract of the engine's multi-GPU path.
+
+Each rank takes its contiguous shard of every point set (pinn_native.parallel.shard_bounds,
+the same helper bench.py and the engine launcher use), evaluates loss/gradient partial sums
+normalised by the GLOBAL set sizes, and an all-reduce(SUM) of [grad | loss] must reproduce the
+single-process result.  The per-shard evaluator here is the CPU oracle standing in for the
+HIP engine (no GPU in this test); on the GPU box the same check runs with the real engine and
+RCCL at world_size 1 (tests/test_gpu_comm.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG, BURGERS_MAT
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(PKG, "1d-burgers"), os.path.join(PKG, "utils")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import burgersutil
+    from oracle import init, pde
+    from pinn_native.parallel import shard_bounds
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, 63, 1001, noise=0.0)     # ragged on purpose
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    layers = [2] + [20] * 8 + [1]
+    w = init.glorot_flat(layers)
+    nu = 0.01 / np.pi
+    f0, f1 = shard_bounds(len(X_f), world, rank)
+    u0, u1 = shard_bounds(len(X_u), world, rank)
+    # collocation partial (global 1/N_f) + data partial (global 1/N_u) for this rank's shards
+    lo_f, g_f, _ = pde.burgers_loss_grad(w, layers, lb, ub, X_f[f0:f1], X_u, u, nu,
+                                         n_f_total=len(X_f), with_data=False)
+    full_u = pde.burgers_loss_grad(w, layers, lb, ub, X_f[:0], X_u[u0:u1], u[u0:u1], nu,
+                                   n_f_total=1)
+    scale = (u1 - u0) / len(X_u)            # mean over the shard -> contribution to the global mean
+    buf = torch.from_numpy(np.concatenate([g_f + scale * full_u[1], [lo_f + scale * full_u[0]]]))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), buf.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_single_process(tmp_path, burgers_sets):
+    from oracle import init, pde
+    import burgersutil
+    port = 29500 + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    red = np.load(tmp_path / "reduced.npy")
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, 63, 1001, noise=0.0)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    layers = [2] + [20] * 8 + [1]
+    lo, g, _ = pde.burgers_loss_grad(init.glorot_flat(layers), layers, lb, ub, X_f, X_u, u,
+                                     0.01 / np.pi)
+    assert abs(red[-1] - lo) < 1e-14
+    assert np.max(np.abs(red[:-1] - g)) / np.max(np.abs(g)) < 1e-13
+
+
+def test_shard_bounds_cover_and_balance():
+    from pinn_native.parallel import shard_bounds
+    for n in (0, 1, 7, 100, 10000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,58 @@
+"""GPU: RCCL path of the engine at world_size 1 (the only size a 1-GPU box allows), and the
+sharding contract with the real kernels: evaluating two shards one after the other on the same
+GPU with global denominators sums to the full-batch gradient."""
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+NU = 0.01 / np.pi
+
+
+def _engine(burgers_sets, dtype):
+    from pinn_native import Engine
+    r = burgers_sets(64, 2048)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    eng = Engine([2] + [20] * 8 + [1], lb, ub, pde="burgers", dtype=dtype)
+    eng.set_pde_params(NU)
+    return eng, X_f, X_u, u
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_rccl_world1_allreduce_is_identity(burgers_sets, dtype):
+    from pinn_native import Engine
+    g = np.load(golden("burgers_eval_small.npz"))
+    eng, X_f, X_u, u = _engine(burgers_sets, dtype)
+    eng.set_collocation(X_f)
+    eng.set_data(X_u, u)
+    eng.set_weights(g["w0"])
+    l0, g0, _ = eng.loss_grad()
+    eng.comm_init(Engine.comm_unique_id(), 1, 0)          # ncclCommInitRank, 1 rank
+    l1, g1, _ = eng.loss_grad()                           # now goes through ncclAllReduce
+    assert l0 == l1 and np.array_equal(g0, g1)
+    eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+    losses = eng.adam_run(3)
+    assert np.all(np.isfinite(losses))
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-12), ("f32", 5e-6)])
+@pytest.mark.parametrize("path", [0, 1])
+def test_shards_with_global_denominators_add_up(burgers_sets, dtype, tol, path):
+    from pinn_native.parallel import attach_shards
+    g = np.load(golden("burgers_eval_small.npz"))
+    eng, X_f, X_u, u = _engine(burgers_sets, dtype)
+    eng.set_kernel_path(path)
+    eng.set_weights(g["w0"])
+    eng.set_collocation(X_f)
+    eng.set_data(X_u, u)
+    l_full, g_full, _ = eng.loss_grad()
+    tot_l, tot_g = 0.0, 0.0
+    for rank in range(3):                                 # 3 ragged shards
+        attach_shards(eng, 3, rank, X_f=X_f, X_u=X_u, u=u)
+        lo, gr, _ = eng.loss_grad()
+        tot_l, tot_g = tot_l + lo, tot_g + gr
+    assert abs(tot_l - l_full) / l_full < tol
+    assert np.max(np.abs(tot_g - g_full)) / np.max(np.abs(g_full)) < tol
+    eng.close()

@@ -1,0 +1,182 @@
+"""CPU: host-side logic of the drop-in surface -- data preparation against the reference's own
+prep_data (golden hashes), the portable custom_lbfgs driver against the reference's lbfgs
+(known-answer fixture), Logger output bytes, the C ABI (library loads, exports every symbol
+of include/pinn_hip.h), and argument validation that needs no GPU."""
+import contextlib
+import ctypes
+import hashlib
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import golden, BURGERS_MAT, NLS_MAT, ROOT
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def test_burgers_prep_data_matches_reference(burgers_sets):
+    g = json.load(open(golden("burgers_data.json")))
+    r = burgers_sets(100, 10000)
+    assert len(r) == 12
+    x, t, X, T, Exact_u, X_star, u_star, X_u, u, X_f, ub, lb = r
+    assert lb.tolist() == g["inf"]["lb"] == [-1.0, 0.0] and ub.tolist() == g["inf"]["ub"]
+    assert X_star.shape == (25600, 2) and X_f.shape == (10000, 2) and X_u.shape == (100, 2)
+    for name, arr in (("X_f", X_f), ("X_u", X_u), ("u", u), ("X_star", X_star), ("u_star", u_star)):
+        assert sha16(arr) == g["inf"]["sha"][name], name
+    assert X_f[0].tolist() == [0.6853359174287899, 0.3944403153496481]
+    r = burgers_sets(64, 2048)
+    assert sha16(r[9]) == g["inf_small"]["sha"]["X_f"] and sha16(r[7]) == g["inf_small"]["sha"]["X_u"]
+
+
+def test_burgers_identification_branch():
+    import burgersutil
+    g = json.load(open(golden("burgers_data.json")))
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, 10000, noise=0.0)
+    assert len(r) == g["ide"]["n_returns"] == 11
+    assert sha16(r[7]) == g["ide"]["sha"]["X_u"] and sha16(r[8]) == g["ide"]["sha"]["u"]
+    assert r[10].tolist() == g["ide"]["lb"] and r[9].tolist() == g["ide"]["ub"]
+    with pytest.raises(NotImplementedError):
+        burgersutil.prep_data(BURGERS_MAT, 10, N_n=5, q=4)
+
+
+def test_schrodinger_prep_data_matches_reference(schrodinger_sets):
+    g = json.load(open(golden("schrodinger_data.json")))
+    r = schrodinger_sets(50, 50, 20000)
+    assert len(r) == 20
+    names = dict(X_f=11, x0=15, tb=14, u0=16, v0=17, X_star=7, h_star=10, u_star=8, v_star=9)
+    for k, i in names.items():
+        assert sha16(r[i]) == g["sha"][k], k
+    assert r[13].tolist() == [-5.0, 0.0] and abs(r[12][1] - np.pi / 2) < 1e-16
+    assert np.all(r[18][:, 1] == 0) and np.array_equal(r[18][:, 0:1], r[15])      # X0 = (x0, 0)
+
+
+def test_lhs_is_a_latin_hypercube():
+    from sampling import lhs
+    np.random.seed(7)
+    H = lhs(2, 50)
+    assert H.shape == (50, 2)
+    for j in range(2):
+        assert sorted(np.floor(H[:, j] * 50).astype(int).tolist()) == list(range(50))
+
+
+def test_custom_lbfgs_known_answer():
+    from custom_lbfgs import lbfgs, Struct
+    import custom_lbfgs
+    k = json.load(open(golden("lbfgs_kat.json")))
+    A = np.diag(np.arange(1.0, 7.0)) + 0.1 * np.ones((6, 6))
+    b = np.arange(1.0, 7.0)
+    args = []
+
+    def opfunc(x):
+        args.append(np.array(x, copy=True))
+        return 0.5 * x @ A @ x - b @ x + 0.25 * np.sum(x ** 4), A @ x - b + x ** 3
+
+    cfg = Struct()
+    cfg.learningRate, cfg.maxIter, cfg.nCorrection = 0.8, 8, 3
+    cfg.tolFun = 1.0 * np.finfo(float).eps
+    logs = []
+    state = Struct()
+    x, f_hist, n_eval = lbfgs(opfunc, np.zeros(6), cfg, state, True,
+                              lambda it, f, is_iter: logs.append((it, f, is_iter)))
+    assert np.allclose(f_hist, k["f_hist"], rtol=0, atol=1e-13)
+    assert np.allclose(x, k["x_returned"], rtol=0, atol=1e-13)
+    assert np.allclose(args[-1], k["last_opfunc_arg"], rtol=0, atol=1e-13)     # model = x_{maxIter-1}
+    assert n_eval == k["n_eval"] == len(args) == 8
+    assert [l[0] for l in logs] == [l[0] for l in k["logs"]] == list(range(1, 8))
+    assert all(l[2] is True for l in logs)
+    assert abs(custom_lbfgs.final_loss - k["final_loss_global"]) < 1e-13
+    assert state.nIter == 8 and state.funcEval == 8 and len(state.old_dirs) == 3
+    cfg0 = Struct()
+    cfg0.maxIter = 0
+    assert lbfgs(opfunc, np.zeros(6), cfg0, Struct(), True, None) is None
+    assert Struct().anything == 0 and k["struct_default"] == 0
+    # initial-point optimality: returns (x, f_hist) only
+    out = lbfgs(lambda z: (0.0, np.zeros(3)), np.ones(3), cfg, Struct(), False, None)
+    assert len(out) == 2
+
+
+def test_logger_bytes_match_reference():
+    from logger import Logger
+    ref = json.load(open(golden("logger_bytes.json")))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        lg = Logger(ref["hp"])
+        lg.set_error_fn(lambda: 0.0123456)
+        lg.start_time = lg.prev_time = 0.0
+        lg.log_train_start(None)
+        lg.log_train_opt("Adam")
+        lg.log_train_epoch(0, 0.26786867)
+        lg.log_train_epoch(7, 0.5)
+        lg.log_train_epoch(20, 0.058455, "l1 = 0.5", True)
+        lg.log_train_end(300)
+    mine, theirs = buf.getvalue(), ref["stdout"]
+
+    def norm(s):
+        s = re.sub(r"elapsed = \d\d:\d\d \(\+\d\d\.\d\)", "elapsed = MM:SS (+SS.S)", s)
+        return re.sub(r"duration = \d\d:\d\d", "duration = MM:SS", s)
+    # everything from "Training started" on is byte-identical (clock fields masked); the three
+    # TensorFlow banner lines are replaced by engine/device lines
+    cut = "\nTraining started"
+    assert norm(mine[mine.index(cut):]) == norm(theirs[theirs.index(cut):])
+    assert mine.startswith("Hyperparameters:\n" + json.dumps(ref["hp"], indent=2) + "\n\n")
+    assert "tf_epoch =      0  elapsed = " in mine and "loss = 2.6787e-01  \n" in mine
+    assert "nt_epoch =     20  " in mine and "loss = 5.8455e-02  l1 = 0.5\n" in mine
+    assert "tf_epoch =      7" not in mine
+    assert "GPU-accerelated: " in mine
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import pinn_native
+    lib = pinn_native.load()
+    header = open(os.path.join(ROOT, "include", "pinn_hip.h")).read()
+    declared = set(re.findall(r"\b(pinn_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(pinn_native.exported_symbols())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pinn_abi_version() == 1
+    # plain C types only in the header
+    code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
+    assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    import pinn_native
+    lib = pinn_native.load()
+    h = ctypes.c_void_p()
+    lb = (ctypes.c_double * 2)(-1.0, 0.0)
+    ub = (ctypes.c_double * 2)(1.0, 1.0)
+    bad = (ctypes.c_int * 3)(3, 20, 1)                    # input dim must be 2
+    rc = lib.pinn_create(ctypes.byref(h), bad, 3, lb, ub, 0, 0, 0)
+    assert rc == -1 and b"input dimension" in lib.pinn_last_error()
+    ragged = (ctypes.c_int * 4)(2, 20, 10, 1)             # unequal hidden widths
+    rc = lib.pinn_create(ctypes.byref(h), ragged, 4, lb, ub, 0, 0, 0)
+    assert rc == -1 and b"hidden widths" in lib.pinn_last_error()
+    ok = (ctypes.c_int * 3)(2, 20, 1)
+    assert lib.pinn_create(ctypes.byref(h), ok, 3, lb, ub, 2, 0, 0) == -1    # Schrodinger needs 2 outputs
+    assert lib.pinn_create(ctypes.byref(h), ok, 3, lb, ub, 0, 7, 0) == -1    # dtype
+    assert lib.pinn_destroy(None) == 0
+
+
+def test_no_cpu_fallback_in_the_product_path():
+    """The product package must not import the oracle (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "pinns-tf2.0_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_engine_construction_fails_loudly_without_gpu():
+    import pinn_native
+    if pinn_native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pinn_native.PinnNativeError):
+        pinn_native.Engine([2, 20, 20, 1], [-1, 0], [1, 1])

@@ -1,0 +1,200 @@
+"""CPU: the oracle (numpy f64 restatement) against the golden fixtures that were produced by
+running the reference's own Python over the test shims (tests/golden/make_golden.py).
+This is what pins the oracle to the reference."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden, BURGERS_MAT
+from oracle import init, mlp, optim, pde
+
+NU = 0.01 / np.pi
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
+def test_burgers_eval(burgers_sets, tag, N_u, N_f):
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    hp = json.loads(str(g["hp"]))
+    r = burgers_sets(N_u, N_f)
+    X_star, X_u, u, X_f, ub, lb = r[5], r[7], r[8], r[9], r[10], r[11]
+    assert np.array_equal(init.glorot_flat(hp["layers"]), g["w0"])       # canonical init
+    assert mlp.n_params(hp["layers"]) == 3021
+    loss, grad, ex = pde.burgers_loss_grad(g["w0"], hp["layers"], lb, ub, X_f, X_u, u, NU)
+    assert abs(loss - float(g["loss"])) < 1e-14
+    assert rel(grad, g["grad"]) < 1e-13
+    assert np.max(np.abs(ex["f"][:64, 0] - g["f_first"])) < 1e-14
+    assert abs(ex["mse_u"] - float(g["mse_u"])) < 1e-14
+    up = mlp.forward_value(mlp.unpack(g["w0"], hp["layers"]), X_star, lb, ub)
+    assert np.max(np.abs(up[::257, 0] - g["u_pred_stride"])) < 1e-14
+
+
+def test_burgers_known_values_from_survey(burgers_sets):
+    """SURVEY.md Appendix C.2 figures (recorded independently of this repo's fixtures)."""
+    g = np.load(golden("burgers_eval.npz"))
+    assert abs(float(g["loss"]) - 0.26786867333002784) < 1e-15
+    assert abs(np.abs(g["grad"]).sum() - 31.975903361883283) < 1e-11
+    assert abs(g["grad"][0] - (-0.034737901273344848)) < 1e-15
+    assert abs(g["grad"][3020] - 0.071065101852763018) < 1e-15
+    assert abs(float(g["err0"]) - 0.91265619374884654) < 1e-14
+
+
+def test_flat_layout_roundtrip():
+    layers = [2, 7, 7, 7, 3]
+    rs = np.random.RandomState(0)
+    w = rs.standard_normal(mlp.n_params(layers))
+    params = mlp.unpack(w, layers)
+    assert [p[0].shape for p in params] == [(2, 7), (7, 7), (7, 7), (7, 3)]
+    assert np.array_equal(mlp.pack(params), w)
+    # W.flatten() row-major then b (utils/neuralnetwork.py:68-78)
+    assert params[0][0][1, 3] == w[1 * 7 + 3] and params[0][1][2] == w[14 + 2]
+
+
+def test_gradient_matches_finite_differences(burgers_sets):
+    r = burgers_sets(64, 2048)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9][:256], r[10], r[11]
+    layers = [2, 6, 6, 6, 1]
+    rs = np.random.RandomState(3)
+    w = 0.5 * rs.standard_normal(mlp.n_params(layers))
+    _, g, _ = pde.burgers_loss_grad(w, layers, lb, ub, X_f, X_u, u, NU)
+    for seed in range(3):
+        v = np.random.RandomState(seed).standard_normal(w.size)
+        v /= np.linalg.norm(v)
+        h = 1e-6
+        fp = pde.burgers_loss_grad(w + h * v, layers, lb, ub, X_f, X_u, u, NU)[0]
+        fm = pde.burgers_loss_grad(w - h * v, layers, lb, ub, X_f, X_u, u, NU)[0]
+        assert abs((fp - fm) / (2 * h) - g @ v) < 1e-7 * max(1.0, abs(g @ v))
+
+
+def test_residual_of_exact_travelling_solution():
+    """u = tanh-free analytic check: for u(x,t) = a x + b t the Burgers residual is b + a(ax+bt);
+    a 1-layer 'network' with tiny weights is linear to O(w^3) -> Taylor channels are consistent."""
+    layers = [2, 4, 1]
+    lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 1.0])
+    rs = np.random.RandomState(5)
+    w = 1e-3 * rs.standard_normal(mlp.n_params(layers))
+    X = rs.uniform(-1, 1, size=(50, 2)) * [1, .5] + [0, .5]
+    (h, p, q, r), _ = mlp.taylor_forward(mlp.unpack(w, layers), X, lb, ub)
+    eps = 1e-5
+    up = mlp.forward_value(mlp.unpack(w, layers), X + [eps, 0], lb, ub)
+    um = mlp.forward_value(mlp.unpack(w, layers), X - [eps, 0], lb, ub)
+    u0 = mlp.forward_value(mlp.unpack(w, layers), X, lb, ub)
+    assert np.max(np.abs((up - um) / (2 * eps) - p)) < 1e-9
+    assert np.max(np.abs((up - 2 * u0 + um) / eps ** 2 - r)) < 1e-5
+    tp = mlp.forward_value(mlp.unpack(w, layers), X + [0, eps], lb, ub)
+    tm = mlp.forward_value(mlp.unpack(w, layers), X - [0, eps], lb, ub)
+    assert np.max(np.abs((tp - tm) / (2 * eps) - q)) < 1e-9
+
+
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048)])
+def test_adam_trajectory(burgers_sets, tag, N_u, N_f):
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    ga = np.load(golden("burgers_adam%s.npz" % tag))
+    hp = json.loads(str(ga["hp"]))
+    r = burgers_sets(N_u, N_f)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    w = g["w0"].copy()
+    adam = optim.Adam(hp["tf_lr"], hp["tf_b1"], eps=hp["tf_eps"])
+    losses = []
+    for it in range(30):
+        lo, gr, _ = pde.burgers_loss_grad(w, hp["layers"], lb, ub, X_f, X_u, u, NU)
+        losses.append(lo)
+        w = adam.step(w, gr)
+        if it == 0:
+            assert rel(w, ga["w_after_1"]) < 1e-13
+    assert np.max(np.abs(np.array(losses) - ga["losses"]) / ga["losses"]) < 1e-10
+    assert rel(w, ga["w_after_30"]) < 1e-10
+
+
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048)])
+def test_lbfgs_trajectory_and_last_iteration_quirk(burgers_sets, tag, N_u, N_f):
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    gl = np.load(golden("burgers_lbfgs%s.npz" % tag))
+    hp = json.loads(str(gl["hp"]))
+    r = burgers_sets(N_u, N_f)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    res = optim.lbfgs(lambda x: pde.burgers_loss_grad(x, hp["layers"], lb, ub, X_f, X_u, u, NU)[:2],
+                      g["w0"], int(gl["max_iter"]), float(gl["lr"]), int(gl["n_corr"]))
+    assert res["n_eval"] == int(gl["n_eval"]) == 25
+    assert [l[0] for l in res["logs"]] == gl["log_iters"].tolist() == list(range(1, 25))
+    assert np.max(np.abs(np.array(res["f_hist"]) - gl["f_hist"]) / gl["f_hist"]) < 1e-10
+    assert rel(res["x"], gl["x_returned"]) < 1e-10
+    assert rel(res["x_model"], gl["w_model"]) < 1e-10
+    assert abs(res["final_loss"] - float(gl["final_loss_global"])) < 1e-12
+
+
+def test_lbfgs_known_answer():
+    k = json.load(open(golden("lbfgs_kat.json")))
+    A = np.diag(np.arange(1.0, 7.0)) + 0.1 * np.ones((6, 6))
+    b = np.arange(1.0, 7.0)
+    args = []
+
+    def opfunc(x):
+        args.append(x.copy())
+        return 0.5 * x @ A @ x - b @ x + 0.25 * np.sum(x ** 4), A @ x - b + x ** 3
+    res = optim.lbfgs(opfunc, np.zeros(6), 8, 0.8, 3)
+    assert np.allclose(res["f_hist"], k["f_hist"], rtol=0, atol=1e-13)
+    assert np.allclose(res["x"], k["x_returned"], rtol=0, atol=1e-13)
+    assert np.allclose(args[-1], k["last_opfunc_arg"], rtol=0, atol=1e-13)
+    assert len(args) == k["n_opfunc_calls"] == 8 and res["n_eval"] == k["n_eval"]
+    assert [l[0] for l in res["logs"]] == [l[0] for l in k["logs"]]
+    assert optim.lbfgs(opfunc, np.zeros(6), 0, 0.8, 3) is None
+
+
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_burgers_identification(tag):
+    import burgersutil
+    g = np.load(golden("burgers_ide_eval%s.npz" % tag))
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.0)
+    layers = [2] + [20] * 8 + [1]
+    loss, grad, ex = pde.burgers_ide_loss_grad(g["w0"], layers, r[10], r[9], r[7], r[8])
+    assert abs(loss - float(g["loss"])) < 1e-14
+    assert rel(grad, g["grad"]) < 1e-12
+    assert abs(grad[-2] - g["grad"][-2]) < 1e-15 and abs(grad[-1] - g["grad"][-1]) < 1e-15
+    assert np.max(np.abs(ex["f"][:64, 0] - g["f_first"])) < 1e-13
+
+
+def test_schrodinger_small(schrodinger_sets):
+    g = np.load(golden("schrodinger_eval_small.npz"))
+    hp = json.loads(str(g["hp"]))
+    r = schrodinger_sets(50, 50, 1024)
+    X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
+    X_lb = np.concatenate((0 * tb + lb[0], tb), 1)
+    X_ub = np.concatenate((0 * tb + ub[0], tb), 1)
+    uv0 = np.concatenate([u0, v0], 1)
+    for mode, Xin in (("compat", np.concatenate([x0, x0], 1)), ("intent", X0)):
+        loss, grad, ex = pde.schrodinger_loss_grad(g["w0"], hp["layers"], lb, ub, X_f, X_lb, X_ub,
+                                                   Xin, uv0)
+        assert abs(loss - float(g["loss_" + mode])) < 1e-13
+        assert rel(grad, g["grad_" + mode]) < 1e-12
+    assert np.max(np.abs(ex["f_u"][:64, 0] - g["f_u_first"])) < 1e-12
+    # Adam (lr .05, b1 .99, eps .1) five steps, compat input as the script does
+    w = g["w0"].copy()
+    adam = optim.Adam(hp["tf_lr"], hp["tf_b1"], eps=hp["tf_eps"])
+    for it in range(5):
+        lo, gr, _ = pde.schrodinger_loss_grad(w, hp["layers"], lb, ub, X_f, X_lb, X_ub,
+                                              np.concatenate([x0, x0], 1), uv0)
+        assert abs(lo - g["adam_losses_compat"][it]) / g["adam_losses_compat"][it] < 1e-10
+        w = adam.step(w, gr)
+    assert rel(w, g["w_after_5"]) < 1e-10
+
+
+def test_shard_sums_equal_full_batch(burgers_sets):
+    """Data-parallel contract: un-normalised shard evaluations (global 1/N) add up to the
+    full-batch loss and gradient."""
+    g = np.load(golden("burgers_eval_small.npz"))
+    r = burgers_sets(64, 2048)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    layers = [2] + [20] * 8 + [1]
+    full = pde.burgers_loss_grad(g["w0"], layers, lb, ub, X_f, X_u, u, NU)
+    tot_l, tot_g = 0.0, 0.0
+    for k, sl in enumerate((slice(0, 700), slice(700, 2048))):
+        lo, gr, _ = pde.burgers_loss_grad(g["w0"], layers, lb, ub, X_f[sl], X_u, u, NU,
+                                          n_f_total=2048, with_data=(k == 0))
+        tot_l, tot_g = tot_l + lo, tot_g + gr
+    assert abs(tot_l - full[0]) < 1e-14 and rel(tot_g, full[1]) < 1e-13
