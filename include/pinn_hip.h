@@ -95,6 +95,10 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
                      double tol_x, double max_eval);
 int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged,
                    int* done);
+/* 0: one-workgroup kernel performing the two-loop recursion in the reference's operation order;
+ * 1 (default, history <= 61): compact form -- all dot products of an iteration in one parallel
+ * kernel, recursion on the Gram matrices.  Same mathematics; rounding differs at 1e-16. */
+int pinn_lbfgs_set_mode(pinn_ctx* c, int mode);
 /* x as custom_lbfgs returns it (:236) -- one step past the model weights */
 int pinn_lbfgs_get_x(pinn_ctx* c, double* x, int64_t n);
 

@@ -106,6 +106,10 @@ struct pinn_ctx {
   double lb_lr = 1.0, lb_tol_fun = 0, lb_tol_x = 0, lb_max_eval = 0;
   int lb_iters_issued = 0;
   bool lb_ready = false;
+  // compact (Gram-matrix) mode
+  int lb_mode = 1, lb_mode_active = 0, lb_M1 = 0;
+  double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
+  LbcExtra* lb_ex = nullptr;
 
   // RCCL
   ncclComm_t comm = nullptr;
@@ -364,7 +368,8 @@ int pinn_destroy(pinn_ctx* c) {
   void* ptrs[] = {c->xs, c->ts, c->tgt, c->theta, c->gl, c->adam_m, c->adam_v, c->theta_r, c->S,
                   c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
-                  c->lb_q, c->lb_log_loss, c->lb_log_iter};
+                  c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
+                  c->lb_cy, c->lb_ex};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -503,12 +508,23 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
         dev_alloc(&c->lb_d, n * 8) || dev_alloc(&c->lb_gold, n * 8) || dev_alloc(&c->lb_q, n * 8))
       return PINN_EHIP;
   }
+  const int M1 = n_corr + 1;                                       // ring slots (compact mode)
+  c->lb_M1 = M1;
+  // compact mode needs the two padded Gram matrices in LDS (<= 64 KiB) and one lane per slot
+  c->lb_mode_active = (c->lb_mode == 1 && M1 <= 62) ? 1 : 0;
   if (n_corr > c->lb_cap_corr) {
-    if (dev_alloc(&c->lb_S, (size_t)n_corr * n * 8) || dev_alloc(&c->lb_Y, (size_t)n_corr * n * 8) ||
-        dev_alloc(&c->lb_ro, (size_t)n_corr * 8) || dev_alloc(&c->lb_al, (size_t)n_corr * 8))
+    if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
+        dev_alloc(&c->lb_ro, (size_t)M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
+        dev_alloc(&c->lb_SY, (size_t)M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)M1 * M1 * 8) ||
+        dev_alloc(&c->lb_dots, (size_t)(5 * M1 + 4) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
+        dev_alloc(&c->lb_cy, (size_t)M1 * 8) || dev_alloc(&c->lb_ex, sizeof(LbcExtra)))
       return PINN_EHIP;
     c->lb_cap_corr = n_corr;
   }
+  HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)M1 * M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)M1 * M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + 4) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_ex, 0, sizeof(LbcExtra), c->stream));
   if (max_iter + 1 > c->lb_cap_log) {
     if (dev_alloc(&c->lb_log_loss, (size_t)(max_iter + 1) * 8) ||
         dev_alloc(&c->lb_log_iter, (size_t)(max_iter + 1) * 4))
@@ -539,7 +555,19 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
   const int n = c->nd.n_theta;
   for (int s = 0; s < n_iters && c->lb_iters_issued < c->lb_max_iter; ++s) {
     c->lb_iters_issued += 1;
-    if (c->dtype == PINN_F64)
+    if (c->lb_mode_active) {
+      const int M1 = c->lb_M1;
+      const size_t lsh = (size_t)2 * M1 * (M1 + 1) * 8;
+      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBC_THREADS), 0, c->stream, n, M1, c->lb_state,
+                         c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+      hipLaunchKernelGGL(k_lbc_coef, dim3(1), dim3(64), lsh, c->stream, M1, c->lb_ncorr,
+                         c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_state, c->lb_ex, c->lb_dots,
+                         c->lb_SY, c->lb_YY, c->lb_ro, c->lb_cs, c->lb_cy);
+      if (c->dtype == PINN_F64)
+        hipLaunchKernelGGL((k_lbc_apply<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r);
+      else
+        hipLaunchKernelGGL((k_lbc_apply<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r);
+    } else if (c->dtype == PINN_F64)
       hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
     else
       hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
@@ -562,6 +590,12 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
   c->lb_logged_read = hs.n_logged;
   if (n_logged) *n_logged = fresh > 0 ? fresh : 0;
   if (done) *done = hs.done;
+  return 0;
+}
+
+int pinn_lbfgs_set_mode(pinn_ctx* c, int mode) {
+  REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (reference operation order) or 1 (compact)");
+  c->lb_mode = mode;
   return 0;
 }
 

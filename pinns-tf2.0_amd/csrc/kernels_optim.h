@@ -226,4 +226,205 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_post(
   if (n_iter == max_iter - 1) st->final_loss = f;      // :223-224
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compact L-BFGS: same iteration as k_lbfgs_step, restructured so that no kernel contains a
+// chain of dependent full-length reductions.
+//   k_lbc_dots   one workgroup per history slot: every dot product this iteration needs
+//                (s_a.y_c, s_c.y_a, y_a.y_c, s_a.g, y_a.g, y_c.s_c, y_c.y_c, g.g, |g|_1) in parallel;
+//                also materialises the candidate pair s_c = t d, y_c = g - g_old.
+//   k_lbc_coef   one wave: accepts the pair (y.s > 1e-10), maintains the Gram matrices
+//                SY[a][b] = s_a.y_b, YY[a][b] = y_a.y_b, and runs the two-loop recursion of
+//                custom_lbfgs.py:126-141 on *scalars* -- every vector of the recursion lives in
+//                span{s_j, y_j, g}, so alpha_i/beta_i follow from the Gram entries alone.
+//                Emits d = cg g + sum_j (cy_j y_j + cs_j s_j), gtd, the step t and the break flag.
+//   k_lbc_apply  d, g_old, x += t d (and the model weights when an evaluation follows).
+// Mathematically identical to the reference recursion; rounding differs at the 1e-16 level.
+// The ring has m+1 slots so that the candidate never overwrites a pair that may still be needed.
+// ---------------------------------------------------------------------------------------------
+struct LbcExtra {
+  int apply, will_eval, pad0, pad1;
+  double cg, gtd;
+};
+
+constexpr int LBC_THREADS = 256;
+
+__device__ __forceinline__ double block_sum256(double v, double* sh) {
+  const double w = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// dots layout: [0,M1) s_a.y_c | [M1,2M1) s_c.y_a | [2M1,3M1) y_a.y_c | [3M1,4M1) s_a.g |
+//              [4M1,5M1) y_a.g | 5M1+0 y_c.s_c | +1 y_c.y_c | +2 g.g | +3 |g|_1
+__global__ __launch_bounds__(LBC_THREADS) void k_lbc_dots(
+    int n, int M1, const LbfgsState* __restrict__ st, const double* __restrict__ g,
+    const double* __restrict__ g_old, const double* __restrict__ d, double* __restrict__ Sh,
+    double* __restrict__ Yh, double* __restrict__ dots) {
+  __shared__ double sh[4];
+  if (st->done) return;
+  const int head = st->hist_head, len = st->hist_len;
+  const bool first = (st->n_iter == 0);
+  const int c = (head + len) % M1;
+  const int a = blockIdx.x;
+  const int pos = (a - head + M1) % M1;
+  const double t = st->t;
+  const int tid = threadIdx.x;
+  if (a == c) {
+    double ys = 0, yy = 0, sg = 0, yg = 0, gg = 0, ga = 0;
+    for (int i = tid; i < n; i += LBC_THREADS) {
+      const double gi = g[i];
+      gg += gi * gi; ga += fabs(gi);
+      if (!first) {
+        const double y = gi - g_old[i], s = d[i] * t;
+        Sh[(size_t)c * n + i] = s; Yh[(size_t)c * n + i] = y;
+        ys += y * s; yy += y * y; sg += s * gi; yg += y * gi;
+      }
+    }
+    ys = block_sum256(ys, sh); yy = block_sum256(yy, sh); sg = block_sum256(sg, sh);
+    yg = block_sum256(yg, sh); gg = block_sum256(gg, sh); ga = block_sum256(ga, sh);
+    if (tid == 0) {
+      dots[5 * M1 + 0] = ys; dots[5 * M1 + 1] = yy; dots[5 * M1 + 2] = gg; dots[5 * M1 + 3] = ga;
+      dots[3 * M1 + c] = sg; dots[4 * M1 + c] = yg;
+    }
+  } else if (pos < len) {
+    double say = 0, sya = 0, yya = 0, sg = 0, yg = 0;
+    for (int i = tid; i < n; i += LBC_THREADS) {
+      const double gi = g[i], sa = Sh[(size_t)a * n + i], ya = Yh[(size_t)a * n + i];
+      const double yc = gi - g_old[i], sc = d[i] * t;
+      say += sa * yc; sya += sc * ya; yya += ya * yc; sg += sa * gi; yg += ya * gi;
+    }
+    say = block_sum256(say, sh); sya = block_sum256(sya, sh); yya = block_sum256(yya, sh);
+    sg = block_sum256(sg, sh); yg = block_sum256(yg, sh);
+    if (tid == 0) {
+      dots[a] = say; dots[M1 + a] = sya; dots[2 * M1 + a] = yya;
+      dots[3 * M1 + a] = sg; dots[4 * M1 + a] = yg;
+    }
+  }
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(64) void k_lbc_coef(
+    int M1, int m, int max_iter, double lr, double tol_x, LbfgsState* __restrict__ st,
+    LbcExtra* __restrict__ ex, const double* __restrict__ dots, double* __restrict__ SY,
+    double* __restrict__ YY, double* __restrict__ ro, double* __restrict__ cs_out,
+    double* __restrict__ cy_out) {
+  extern __shared__ double lsh[];
+  const int lane = threadIdx.x;
+  const int LD = M1 + 1;                       // padded leading dimension (bank spread)
+  double* sSY = lsh;
+  double* sYY = lsh + M1 * LD;
+  if (st->done) { if (lane == 0) ex->apply = 0; return; }
+  const int n_iter = uni(st->n_iter) + 1;
+  const bool first = (n_iter == 1);
+  int head = uni(st->hist_head), len = uni(st->hist_len);
+  const int c = (head + len) % M1;
+  double Hdiag = st->Hdiag;
+  const double gg = dots[5 * M1 + 2], gabs = dots[5 * M1 + 3];
+
+  for (int e = lane; e < M1 * M1; e += 64) {
+    const int r = e / M1, q = e - r * M1;
+    sSY[r * LD + q] = SY[e];
+    sYY[r * LD + q] = YY[e];
+  }
+  __syncthreads();
+  if (!first) {
+    const double ys = dots[5 * M1 + 0], yy = dots[5 * M1 + 1];
+    if (ys > 1e-10) {                           // custom_lbfgs.py:102-114
+      if (lane < M1) {
+        const double sya = (lane == c) ? ys : dots[M1 + lane];       // s_c . y_lane
+        const double say = (lane == c) ? ys : dots[lane];            // s_lane . y_c
+        const double yya = (lane == c) ? yy : dots[2 * M1 + lane];
+        sSY[c * LD + lane] = sya; SY[c * M1 + lane] = sya;
+        sSY[lane * LD + c] = say; SY[lane * M1 + c] = say;
+        sYY[c * LD + lane] = yya; YY[c * M1 + lane] = yya;
+        sYY[lane * LD + c] = yya; YY[lane * M1 + c] = yya;
+      }
+      if (lane == 0) ro[c] = 1.0 / ys;
+      Hdiag = ys / yy;
+      if (len == m) head = (head + 1) % M1; else len += 1;
+    }
+  }
+  __syncthreads();
+  const int my_pos = (lane - head + M1) % M1;
+  const bool my_in = lane < M1 && my_pos < len;
+  const double my_sg = my_in ? dots[3 * M1 + lane] : 0.0;
+  const double my_yg = my_in ? dots[4 * M1 + lane] : 0.0;
+  double my_ro = 0.0;
+  if (my_in) my_ro = (!first && lane == c && dots[5 * M1 + 0] > 1e-10) ? 1.0 / dots[5 * M1 + 0] : ro[lane];
+
+  // backward loop: al_i = ro_i * (s_i . q_i),  q_i = -g - sum_{j>i} al_j y_j
+  double al = 0.0;
+  for (int i = len - 1; i >= 0; --i) {
+    const int si = (head + i) % M1;
+    const double term = (my_in && my_pos > i) ? al * sSY[si * LD + lane] : 0.0;
+    const double sum = wave_sum(term);
+    const double a_i = read_lane(my_ro, si) * (-read_lane(my_sg, si) - sum);
+    if (lane == si) al = a_i;
+  }
+  // y_a . q_0,  q_0 = -g - sum_j al_j y_j   (lane-parallel)
+  double yq0 = -my_yg;
+  for (int p = 0; p < len; ++p) {
+    const int sj = (head + p) % M1;
+    const double al_j = read_lane(al, sj);
+    if (my_in) yq0 -= al_j * sYY[lane * LD + sj];
+  }
+  // forward loop: be_i = ro_i * y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j),  cs_i = al_i - be_i
+  double cs = 0.0;
+  for (int i = 0; i < len; ++i) {
+    const int si = (head + i) % M1;
+    const double term = (my_in && my_pos < i) ? cs * sSY[lane * LD + si] : 0.0;
+    const double sum = wave_sum(term);
+    const double be_i = read_lane(my_ro, si) * (Hdiag * read_lane(yq0, si) + sum);
+    const double c_i = read_lane(al, si) - be_i;
+    if (lane == si) cs = c_i;
+  }
+  const double cy = -Hdiag * al;
+  const double cg = -Hdiag;
+  const double gtd = cg * gg + wave_sum(my_in ? (cy * my_yg + cs * my_sg) : 0.0);
+  if (lane < M1) { cs_out[lane] = my_in ? cs : 0.0; cy_out[lane] = my_in ? cy : 0.0; }
+  if (lane == 0) {
+    st->n_iter = n_iter; st->hist_len = len; st->hist_head = head; st->Hdiag = Hdiag;
+    st->f_old = st->f;
+    ex->cg = cg; ex->gtd = gtd;
+    if (gtd > -tol_x) {                          // custom_lbfgs.py:154-156
+      st->done = 2; ex->apply = 0; ex->will_eval = 0;
+    } else {
+      double t;
+      if (first) { const double inv = 1.0 / gabs; t = inv < 1.0 ? inv : 1.0; } else t = lr;
+      st->t = t;
+      ex->apply = 1;
+      ex->will_eval = (n_iter != max_iter) ? 1 : 0;
+      if (n_iter == max_iter) st->done = 1;      // :192
+    }
+  }
+}
+
+template <typename real>
+__global__ void k_lbc_apply(int n, int M1, const LbfgsState* __restrict__ st,
+                            const LbcExtra* __restrict__ ex, const double* __restrict__ g,
+                            const double* __restrict__ Sh, const double* __restrict__ Yh,
+                            const double* __restrict__ cs, const double* __restrict__ cy,
+                            double* __restrict__ d, double* __restrict__ g_old,
+                            double* __restrict__ x, double* __restrict__ theta,
+                            real* __restrict__ theta_r) {
+  if (!ex->apply) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int head = st->hist_head, len = st->hist_len;
+  const double gi = g[i];
+  double di = ex->cg * gi;
+  for (int p = 0; p < len; ++p) {
+    const int sj = (head + p) % M1;
+    di += cy[sj] * Yh[(size_t)sj * n + i] + cs[sj] * Sh[(size_t)sj * n + i];
+  }
+  d[i] = di;
+  g_old[i] = gi;
+  const double xi = x[i] + st->t * di;
+  x[i] = xi;
+  if (ex->will_eval) { theta[i] = xi; theta_r[i] = (real)xi; }
+}
+
 }  // namespace pinn

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "pinn_lbfgs_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p, _c_double_p,
                                       _c_int_p, _c_int_p]),
     "pinn_lbfgs_get_x": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
@@ -270,6 +271,9 @@ class Engine(object):
         self._lb_max_iter = int(max_iter)
         self._check(self._lib.pinn_lbfgs_begin(self._h, int(max_iter), lr, int(n_corr), tol_fun,
                                                tol_x, max_eval))
+
+    def lbfgs_set_mode(self, mode):
+        self._check(self._lib.pinn_lbfgs_set_mode(self._h, int(mode)))
 
     def lbfgs_run(self, n_iters):
         cap = max(int(n_iters), 1)

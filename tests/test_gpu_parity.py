@@ -116,11 +116,13 @@ def test_burgers_adam_trajectory(burgers_sets, dtype, tag, N_u, N_f):
     eng.close()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
-def test_burgers_lbfgs_trajectory_f64(burgers_sets, tag, N_u, N_f):
+def test_burgers_lbfgs_trajectory_f64(burgers_sets, tag, N_u, N_f, mode):
     g = np.load(golden("burgers_eval%s.npz" % tag))
     gl = np.load(golden("burgers_lbfgs%s.npz" % tag))
     eng, *_ = make_burgers(burgers_sets, N_u, N_f, "f64")
+    eng.lbfgs_set_mode(mode)
     eng.set_weights(g["w0"])
     eng.lbfgs_begin(int(gl["max_iter"]), float(gl["lr"]), int(gl["n_corr"]), np.finfo(float).eps)
     it_all, lo_all, done = [], [], 0
