@@ -114,15 +114,20 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n);
 int pinn_comm_unique_id(char* id128);
 int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank);
 
-/* Measurement: bracket every launch of the dominant kernel (the loss+grad kernels) with
- * hipEvents on the engine's stream.  pinn_timing_read drains them: avg_ms[0] forward sweep,
- * avg_ms[1] reverse sweep, avg_ms[2] whole evaluation; n = evaluations timed. */
-int pinn_timing_enable(pinn_ctx* c, int max_evals);
+/* Measurement: bracket launches of the dominant kernel (the loss+grad kernels) with hipEvents
+ * on the engine's stream.  An event record costs ~5 us on the GPU timeline, so only one
+ * evaluation out of `every` is sampled (at most max_evals samples).  pinn_timing_read drains
+ * them: avg_ms[0] forward sweep, avg_ms[1] forward+reverse sweeps, avg_ms[2] whole evaluation;
+ * n = evaluations sampled. */
+int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);
 int pinn_sync(pinn_ctx* c);
 /* which kernel family serves the loss+grad evaluation: 0 generic, 1 fused width-20 */
 int pinn_set_kernel_path(pinn_ctx* c, int path);
 int pinn_get_kernel_path(pinn_ctx* c, int* path);
+/* Profiling build (-DPINN_STAMPS) only: one evaluation with a per-wave s_memtime timeline of the
+ * fused kernel; out[wave][32] ticks, n_waves = 4 x workgroups.  PINN_EUNSUPPORTED otherwise. */
+int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,7 @@ struct pinn_ctx {
   int lb_max_iter = 0, lb_ncorr = 0, lb_cap_corr = 0, lb_cap_log = 0, lb_logged_read = 0;
   double lb_lr = 1.0, lb_tol_fun = 0, lb_tol_x = 0, lb_max_eval = 0;
   int lb_iters_issued = 0;
+  bool lb_post_pending = false;      // an evaluation whose break tests / log entry are still due
   bool lb_ready = false;
   // compact (Gram-matrix) mode
   int lb_mode = 1, lb_mode_active = 0, lb_M1 = 0;
@@ -115,9 +116,12 @@ struct pinn_ctx {
   ncclComm_t comm = nullptr;
   int n_ranks = 1, rank = 0;
 
+  // per-wave phase timeline of the fused kernel (profiling build only)
+  long long* stamps = nullptr;
   // timing
   std::vector<hipEvent_t> ev;
-  int ev_used = 0, ev_cap_evals = 0;
+  int ev_used = 0, ev_cap_evals = 0, ev_every = 1;
+  int64_t ev_seen = 0;
   bool timing = false;
 };
 
@@ -219,8 +223,13 @@ static int ensure_sets(pinn_ctx* c) {
 // ------------------------------------------------------------------------------------------
 // one loss+gradient evaluation at the current weights -> c->gl  (no host sync)
 // ------------------------------------------------------------------------------------------
+struct AdamFuse {          // single-GPU Adam step applied by the reduction kernel itself
+  double alpha;
+  double* loss3;
+};
+
 template <typename real, int PDE>
-static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4) {
+static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   constexpr int JT = sizeof(real) == 4 ? 20 : 10;
   constexpr int KT = sizeof(real) == 4 ? 10 : 5;
   const SetDesc sd = c->sd;
@@ -231,7 +240,7 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
                                              (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
                                              st, (real)c->nu, (vec4<real>*)c->S, (real*)c->part, c->R,
-                                             c->stream);
+                                             c->stream, c->stamps);
     if (rc) return fail(PINN_EHIP, "fused20 launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
   } else {
@@ -252,22 +261,30 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4) {
     }
   }
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
-  hipLaunchKernelGGL((k_reduce_rows<real>), dim3((c->R + 255) / 256), dim3(256), 0, c->stream,
-                     (const real*)c->part, c->path == 1 ? fused20_rows(sd) : c->n_rows, c->R, c->gl);
+  const int n_rows = c->path == 1 ? fused20_rows(sd) : c->n_rows;
+  const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
+  if (af)
+    hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
+                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3);
+  else
+    hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int eval_loss_grad(pinn_ctx* c) {
+static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
   int rc = ensure_sets(c);
   if (rc) return rc;
   hipEvent_t* ev4 = nullptr;
-  if (c->timing && c->ev_used < c->ev_cap_evals) ev4 = &c->ev[(size_t)4 * c->ev_used];
+  if (c->timing && c->ev_used < c->ev_cap_evals && (c->ev_seen++ % c->ev_every) == 0)
+    ev4 = &c->ev[(size_t)4 * c->ev_used];
 #define DISPATCH(REAL)                                                       \
   switch (c->pde) {                                                          \
-    case PINN_PDE_BURGERS: rc = launch_sweeps<REAL, 0>(c, ev4); break;       \
-    case PINN_PDE_BURGERS_IDE: rc = launch_sweeps<REAL, 1>(c, ev4); break;   \
-    default: rc = launch_sweeps<REAL, 2>(c, ev4); break;                     \
+    case PINN_PDE_BURGERS: rc = launch_sweeps<REAL, 0>(c, ev4, af); break;       \
+    case PINN_PDE_BURGERS_IDE: rc = launch_sweeps<REAL, 1>(c, ev4, af); break;   \
+    default: rc = launch_sweeps<REAL, 2>(c, ev4, af); break;                     \
   }
   if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
 #undef DISPATCH
@@ -468,17 +485,23 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
   HIPCHK(hipSetDevice(c->device));
   if (n_steps == 0) return 0;
   if (losses && (size_t)n_steps > c->cap_loss_hist) {
-    if (dev_alloc(&c->loss_hist, (size_t)n_steps * 8)) return PINN_EHIP;
+    if (dev_alloc(&c->loss_hist, (size_t)n_steps * 3 * 8)) return PINN_EHIP;
     c->cap_loss_hist = n_steps;
   }
   const int n = c->nd.n_theta;
   for (int s = 0; s < n_steps; ++s) {
-    int rc = eval_loss_grad(c);
-    if (rc) return rc;
     c->adam_t += 1;
     const double t = (double)c->adam_t;
     const double alpha = c->lr * std::sqrt(1.0 - std::pow(c->b2, t)) / (1.0 - std::pow(c->b1, t));
-    double* slot = losses ? c->loss_hist + s : nullptr;
+    double* slot = losses ? c->loss_hist + (size_t)3 * s : nullptr;
+    if (!c->comm) {                               // reduction + update in one kernel
+      const AdamFuse af{alpha, slot};
+      int rc = eval_loss_grad(c, &af);
+      if (rc) return rc;
+      continue;
+    }
+    int rc = eval_loss_grad(c);                   // reduce -> RCCL all-reduce -> update
+    if (rc) return rc;
     if (c->dtype == PINN_F64)
       hipLaunchKernelGGL((k_adam<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (double*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n);
     else
@@ -486,8 +509,10 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
   }
   HIPCHK(hipGetLastError());
   if (losses) {
-    HIPCHK(hipMemcpyAsync(losses, c->loss_hist, (size_t)n_steps * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<double> h3((size_t)3 * n_steps);
+    HIPCHK(hipMemcpyAsync(h3.data(), c->loss_hist, h3.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < n_steps; ++s) losses[s] = h3[3 * s] + h3[3 * s + 1] + h3[3 * s + 2];
   }
   return 0;
 }
@@ -500,7 +525,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   c->lb_max_iter = max_iter; c->lb_lr = lr; c->lb_ncorr = n_corr;
   c->lb_tol_fun = tol_fun; c->lb_tol_x = tol_x;
   c->lb_max_eval = max_eval > 0 ? max_eval : 1.25 * max_iter;     // custom_lbfgs.py:50
-  c->lb_iters_issued = 0; c->lb_logged_read = 0;
+  c->lb_iters_issued = 0; c->lb_logged_read = 0; c->lb_post_pending = false;
   c->lb_ready = false;
   if (max_iter == 0) { c->lb_ready = true; return 0; }           // custom_lbfgs.py:43-44
   if (!c->lb_state) {
@@ -516,14 +541,14 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
         dev_alloc(&c->lb_ro, (size_t)M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_SY, (size_t)M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)M1 * M1 * 8) ||
-        dev_alloc(&c->lb_dots, (size_t)(5 * M1 + 4) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
+        dev_alloc(&c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_cy, (size_t)M1 * 8) || dev_alloc(&c->lb_ex, sizeof(LbcExtra)))
       return PINN_EHIP;
     c->lb_cap_corr = n_corr;
   }
   HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)M1 * M1 * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)M1 * M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + 4) * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + LBC_NSCAL) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_ex, 0, sizeof(LbcExtra), c->stream));
   if (max_iter + 1 > c->lb_cap_log) {
     if (dev_alloc(&c->lb_log_loss, (size_t)(max_iter + 1) * 8) ||
@@ -557,16 +582,20 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     c->lb_iters_issued += 1;
     if (c->lb_mode_active) {
       const int M1 = c->lb_M1;
-      const size_t lsh = (size_t)2 * M1 * (M1 + 1) * 8;
+      const size_t lsh = (size_t)2 * M1 * lbc_ld(M1) * 8;
       hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBC_THREADS), 0, c->stream, n, M1, c->lb_state,
                          c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
-      hipLaunchKernelGGL(k_lbc_coef, dim3(1), dim3(64), lsh, c->stream, M1, c->lb_ncorr,
-                         c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_state, c->lb_ex, c->lb_dots,
-                         c->lb_SY, c->lb_YY, c->lb_ro, c->lb_cs, c->lb_cy);
+      hipLaunchKernelGGL(k_lbc_coef, dim3(1), dim3(LBC_THREADS), lsh, c->stream, M1, c->lb_ncorr,
+                         c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun, c->lb_max_eval,
+                         c->lb_post_pending ? 1 : 0, n, c->lb_state, c->lb_ex, c->gl, c->lb_dots,
+                         c->lb_SY, c->lb_YY, c->lb_ro, c->lb_cs, c->lb_cy, c->lb_log_iter,
+                         c->lb_log_loss);
+      c->lb_post_pending = false;
+      const dim3 agrid((n + 63) / 64);
       if (c->dtype == PINN_F64)
-        hipLaunchKernelGGL((k_lbc_apply<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r);
+        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r);
       else
-        hipLaunchKernelGGL((k_lbc_apply<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r);
+        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r);
     } else if (c->dtype == PINN_F64)
       hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
     else
@@ -574,9 +603,16 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
     int rc = eval_loss_grad(c);
     if (rc) return rc;
+    if (c->lb_mode_active) { c->lb_post_pending = true; continue; }   // folded into the next k_lbc_coef
     hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
                        c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state, c->gl, c->lb_d,
                        c->lb_log_iter, c->lb_log_loss, 0);
+  }
+  if (c->lb_post_pending) {                       // the host is about to read the state: settle it
+    hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
+                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state, c->gl, c->lb_d,
+                       c->lb_log_iter, c->lb_log_loss, 0);
+    c->lb_post_pending = false;
   }
   HIPCHK(hipGetLastError());
   LbfgsState hs;
@@ -699,8 +735,8 @@ int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank) {
   return 0;
 }
 
-int pinn_timing_enable(pinn_ctx* c, int max_evals) {
-  REQUIRE(c && max_evals >= 0, "bad arguments");
+int pinn_timing_enable(pinn_ctx* c, int max_evals, int every) {
+  REQUIRE(c && max_evals >= 0 && every >= 1, "bad arguments");
   HIPCHK(hipSetDevice(c->device));
   while ((int)c->ev.size() < 4 * max_evals) {
     hipEvent_t e;
@@ -708,6 +744,7 @@ int pinn_timing_enable(pinn_ctx* c, int max_evals) {
     c->ev.push_back(e);
   }
   c->ev_cap_evals = max_evals; c->ev_used = 0; c->timing = max_evals > 0;
+  c->ev_every = every; c->ev_seen = 0;
   return 0;
 }
 
@@ -744,6 +781,31 @@ int pinn_set_kernel_path(pinn_ctx* c, int path) {
   c->path = path;
   c->sets_dirty = true;
   return 0;
+}
+
+int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves) {
+#ifdef PINN_STAMPS
+  REQUIRE(c && out && n_waves, "null");
+  REQUIRE(c->path == 1, "stamps exist for the fused kernel only");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_sets(c);
+  if (rc) return rc;
+  const size_t n = (size_t)c->sd.n_pad / 64 * 4 * 32;
+  REQUIRE((size_t)cap >= n, "stamp buffer too small: need %zu", n);
+  if (dev_alloc(&c->stamps, n * 8)) return PINN_EHIP;
+  HIPCHK(hipMemsetAsync(c->stamps, 0, n * 8, c->stream));
+  rc = eval_loss_grad(c);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->stamps, n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(c->stamps);
+  c->stamps = nullptr;
+  *n_waves = (int64_t)(n / 32);
+  return 0;
+#else
+  (void)c; (void)out; (void)cap; (void)n_waves;
+  return fail(PINN_EUNSUPPORTED, "built without -DPINN_STAMPS (profiling build only)");
+#endif
 }
 
 int pinn_get_kernel_path(pinn_ctx* c, int* path) {

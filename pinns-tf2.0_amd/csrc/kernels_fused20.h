@@ -101,6 +101,18 @@ __device__ __forceinline__ double tanh_bf(double x) {
   return copysign((1.0 - t) / (1.0 + t), x);
 }
 
+// Optional per-wave phase timeline (s_memtime ticks), compiled in only with -DPINN_STAMPS
+// (the profiling build libpinn_hip_stamps.so); see profiles/stamps.py.
+#ifdef PINN_STAMPS
+#define STAMP(i)                                                                   \
+  do {                                                                             \
+    if (stamps && (threadIdx.x & 63) == 0)                                         \
+      stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + (i)] = clock64(); \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 template <typename real, int PDE>
 __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
                                                  const real* __restrict__ th,
@@ -109,7 +121,8 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
                                                  const real* __restrict__ tgt, real lbx, real lbt,
                                                  real sx, real st, real nu,
                                                  vec4<real>* __restrict__ S,
-                                                 real* __restrict__ part, int R) {
+                                                 real* __restrict__ part, int R,
+                                                 long long* __restrict__ stamps) {
   using TR = FusedTraits<real>;
   using acc_t = typename TR::acc_t;
   constexpr int RS4 = TR::RS4;
@@ -118,6 +131,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
   extern __shared__ __attribute__((aligned(32))) unsigned char lds_raw[];
   vec4<real>* const lds = reinterpret_cast<vec4<real>*>(lds_raw);
 
+  STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,6 +186,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
     }
   }
   __syncthreads();                        // weights staged + layer-0 tile published
+  STAMP(1);
   int cur = 0;
   for (int d = 1; d < H; ++d) {
     const vec4<real>* __restrict__ Xin = BUF(cur);
@@ -204,6 +219,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
     }
     cur ^= 1;
     lds_barrier();
+    STAMP(1 + d);
   }
   // linear output layer (every wave computes it: 80 FMAs) -> o = (u, u_x, u_t, u_xx)
   vec4<real> o{th[nd.off_b[H]], 0, 0, 0};
@@ -277,6 +293,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
     }
   }
   lds_barrier();          // every wave is done reading the forward tile before it is overwritten
+  STAMP(H + 1);
 
   const int ti = wave >> 1, tj = wave & 1;                    // this wave's 16x16 tile of dW
   const int fa = min(16 * ti + (lane & 15), FW);              // A row: input feature (20 = ones)
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) { cur_s[kk] = prev_s[kk]; prev_s[kk] = next_s[kk]; }
     if (TR::NBUF == 2) pair ^= 1; else lds_barrier();
+    STAMP(2 * H + 1 - d);
   }
   {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
     real kx = 0, kt = 0, kb = 0;
@@ -357,13 +375,15 @@ __global__ __launch_bounds__(256) void k_fused20(NetDesc nd, SetDesc sd,
       row[nd.off_b[0] + j0 + lane] = kb;
     }
   }
+  STAMP(2 * H + 1);
 }
 
 // returns a hipError_t (0 = ok)
 template <typename real, int PDE>
 inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, const real* xs,
                           const real* ts, const real* tgt, real lbx, real lbt, real sx, real st,
-                          real nu, vec4<real>* S, real* part, int R, hipStream_t stream) {
+                          real nu, vec4<real>* S, real* part, int R, hipStream_t stream,
+                          long long* stamps = nullptr) {
   const size_t lds = fused20_lds_bytes<real>(nd.n_hidden);
   static size_t attr_set = 0;
   if (attr_set < lds) {
@@ -373,7 +393,7 @@ inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, 
     attr_set = lds;
   }
   hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
-                     xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R);
+                     xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R, stamps);
   return (int)hipGetLastError();
 }
 

@@ -38,23 +38,27 @@ def _stale():
     return any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, stamps=False):
     """Compile the HIP engine for gfx950 into pinn_native/libpinn_hip.so (in-tree, so the
-    shared object travels with the repo snapshot).  hipcc cross-compiles without a GPU."""
-    if not force and not _stale():
+    shared object travels with the repo snapshot).  hipcc cross-compiles without a GPU.
+    stamps=True builds the profiling variant libpinn_hip_stamps.so (-DPINN_STAMPS) instead."""
+    out = LIB_PATH.replace(".so", "_stamps.so") if stamps else LIB_PATH
+    if not force and not stamps and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           os.path.join(_CSRC, "engine.hip"), "-o", LIB_PATH + ".tmp", "-lrccl"]
+           os.path.join(_CSRC, "engine.hip"), "-o", out + ".tmp", "-lrccl"]
+    if stamps:
+        cmd.insert(1, "-DPINN_STAMPS")
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise PinnNativeError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
-    return LIB_PATH
+    os.replace(out + ".tmp", out)
+    return out
 
 
 _LIB = None
@@ -95,11 +99,13 @@ _SIGNATURES = {
     "pinn_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pinn_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int,
                                       ctypes.c_int]),
-    "pinn_timing_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pinn_timing_enable": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     "pinn_timing_read": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_int_p]),
     "pinn_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "pinn_set_kernel_path": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_get_kernel_path": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
+    "pinn_debug_stamps": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong),
+                                         ctypes.c_int64, ctypes.POINTER(ctypes.c_int64)]),
 }
 
 
@@ -304,8 +310,8 @@ class Engine(object):
         self._check(self._lib.pinn_comm_init(self._h, bytes(unique_id), int(n_ranks), int(rank)))
 
     # ---- measurement -----------------------------------------------------------------------
-    def timing_enable(self, max_evals):
-        self._check(self._lib.pinn_timing_enable(self._h, int(max_evals)))
+    def timing_enable(self, max_evals, every=1):
+        self._check(self._lib.pinn_timing_enable(self._h, int(max_evals), int(every)))
 
     def timing_read(self):
         ms = np.zeros(3, dtype=np.float64)
@@ -318,6 +324,15 @@ class Engine(object):
 
     def set_kernel_path(self, path):
         self._check(self._lib.pinn_set_kernel_path(self._h, int(path)))
+
+    def debug_stamps(self):
+        """(profiling build) -> int64 array [n_waves, 32] of s_memtime ticks for one evaluation"""
+        n_wg = (2 * self.n_b + self.n_u + self.n_f + 63) // 64
+        buf = np.zeros((n_wg * 4, 32), dtype=np.int64)
+        n = ctypes.c_int64(0)
+        self._check(self._lib.pinn_debug_stamps(
+            self._h, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), buf.size, ctypes.byref(n)))
+        return buf[:n.value]
 
     def kernel_path(self):
         p = ctypes.c_int(0)

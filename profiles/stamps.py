@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-wave phase timeline of the fused loss+grad kernel (profiling build, -DPINN_STAMPS).
+
+    PINN_HIP_LIB=pinns-tf2.0_amd/pinn_native/libpinn_hip_stamps.so python profiles/stamps.py [f32|f64] [N_f]
+
+Prints, for the median workgroup, the s_memtime ticks spent per phase (max over its 4 waves)
+and the spread of workgroup start/end times across the grid."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (sets sys.path for the package)
+import burgersutil  # noqa: E402
+import pinn_native  # noqa: E402
+
+
+def main():
+    dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+    n_f = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    np.random.seed(1234)
+    r = burgersutil.prep_data(os.path.join(bench.PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, n_f, noise=0.0)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    eng = pinn_native.Engine(bench.LAYERS, lb, ub, pde="burgers", dtype=dtype)
+    eng.set_collocation(X_f)
+    eng.set_data(X_u, u)
+    eng.set_pde_params(bench.NU)
+    eng.set_weights(bench.canonical_weights())
+    for _ in range(3):
+        eng.loss_grad()
+    st = eng.debug_stamps().astype(np.float64)          # [n_waves, 32]
+    H = len(bench.LAYERS) - 2
+    n_st = 2 * H + 2
+    st = st[:, :n_st].reshape(-1, 4, n_st)              # [wg, wave, stamp]
+    t0 = st[:, :, 0].min()
+    names = (["stage weights + dense0"] + ["fwd dense %d" % d for d in range(1, H)] +
+             ["output + seeds + bwd dense %d" % H] + ["bwd dense %d" % d for d in range(H - 1, 0, -1)] +
+             ["bwd dense 0 + stores"])
+    dur = np.diff(st, axis=2)                           # [wg, wave, phase]
+    wg_total = st[:, :, -1].max(axis=1) - st[:, :, 0].min(axis=1)
+    print("# %s N_f=%d workgroups=%d  (ticks = shader cycles via s_memtime)" % (dtype, n_f, st.shape[0]))
+    print("# workgroup duration ticks: min %.0f median %.0f max %.0f" % (wg_total.min(), np.median(wg_total), wg_total.max()))
+    print("# first start -> last end: %.0f ticks; start spread %.0f ticks" % (
+        st[:, :, -1].max() - t0, st[:, :, 0].min(axis=1).max() - t0))
+    print("%-34s %10s %10s %10s" % ("phase", "median", "min", "max"))
+    per = dur.max(axis=1)                               # slowest wave per wg
+    for i, nme in enumerate(names):
+        print("%-34s %10.0f %10.0f %10.0f" % (nme, np.median(per[:, i]), per[:, i].min(), per[:, i].max()))
+    print("%-34s %10.0f" % ("sum of medians", np.median(per, axis=0).sum()))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
