@@ -14,6 +14,7 @@
 
 #include "../../include/pinn_hip.h"
 #include "kernels_fused20.h"
+#include "kernels_fused20r.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
 
@@ -80,6 +81,8 @@ struct pinn_ctx {
   // device: parameters / optimiser (float64) + compute-dtype mirror
   double *theta = nullptr, *gl = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   void* theta_r = nullptr;
+  float* img = nullptr;              // packed hidden-layer weights for k_fused20r (f32 only)
+  int n_cu = 256, n_wg = 0;          // compute units; workgroups of the persistent kernel
   // device: scratch
   void *S = nullptr, *O = nullptr, *ZA = nullptr, *ZB = nullptr, *part = nullptr;
   size_t cap_S = 0, cap_O = 0, cap_Z = 0, cap_part = 0, cap_pts = 0;
@@ -133,6 +136,12 @@ static bool fused_ok(const pinn_ctx* c) {
   const size_t lds = c->dtype == PINN_F64 ? fused20_lds_bytes<double>(c->nd.n_hidden)
                                           : fused20_lds_bytes<float>(c->nd.n_hidden);
   return lds <= 160 * 1024;
+}
+
+// the register-stash kernel: float32, width 20, instantiated depths, weights + tiles within LDS
+static bool fused_regs_ok(const pinn_ctx* c) {
+  return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER &&
+         c->nd.n_hidden == 8 && fused20r_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
 }
 
 template <typename T>
@@ -206,8 +215,10 @@ static int ensure_sets(pinn_ctx* c) {
   const size_t W = c->nd.width, H = c->nd.n_hidden;
   // the fused kernel keeps the whole set's stash (one launch); the generic path works in chunks
   const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
-  const size_t rows = c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
-  const size_t need_S = H * W * stash_pts * 4 * rs, need_Z = W * (size_t)c->chunk * 4 * rs;
+  c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (path 2)
+  const size_t rows = c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
+  const size_t need_S = c->path == 2 ? 16 : H * W * stash_pts * 4 * rs;
+  const size_t need_Z = c->path == 2 ? 16 : W * (size_t)c->chunk * 4 * rs;
   const size_t need_part = rows * c->R * rs;
   if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
   if (need_Z > c->cap_Z) {
@@ -236,7 +247,16 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
   const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
   if (ev4) HIPCHK(hipEventRecord(ev4[0], c->stream));
-  if (c->path == 1) {
+  if (c->path == 2) {
+    int rc = hipErrorInvalidValue;
+    if constexpr (sizeof(real) == 4 && PDE != 2)
+      rc = fused20r_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+                                   (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
+                                   (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
+                                   c->stream, c->stamps);
+    if (rc) return fail(PINN_EHIP, "fused20r launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
+  } else if (c->path == 1) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
                                              (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
                                              st, (real)c->nu, (vec4<real>*)c->S, (real*)c->part, c->R,
@@ -261,12 +281,12 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     }
   }
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
-  const int n_rows = c->path == 1 ? fused20_rows(sd) : c->n_rows;
+  const int n_rows = c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
   const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
   if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
-                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3);
+                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img);
   else
     hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl);
@@ -297,9 +317,9 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
 static int cast_weights(pinn_ctx* c) {
   const int n = c->nd.n_theta;
   if (c->dtype == PINN_F64)
-    hipLaunchKernelGGL((k_cast_weights<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (double*)c->theta_r);
+    hipLaunchKernelGGL((k_cast_weights<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (double*)c->theta_r, c->nd, c->img);
   else
-    hipLaunchKernelGGL((k_cast_weights<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (float*)c->theta_r);
+    hipLaunchKernelGGL((k_cast_weights<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->theta, (float*)c->theta_r, c->nd, c->img);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -371,8 +391,19 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   HIPCHK(hipMemsetAsync(c->theta_r, 0, n * real_size(c), c->stream));
   HIPCHK(hipMemsetAsync(c->gl, 0, (size_t)c->R * 8, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  // width-20 Burgers nets take the fused path by default
-  c->path = fused_ok(c) ? 1 : 0;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      c->n_cu = prop.multiProcessorCount;
+  }
+  if (fused_regs_ok(c)) {
+    const size_t nimg = fused20r_image_floats(nd.n_hidden);
+    if (dev_alloc(&c->img, nimg * 4)) { delete c; return PINN_EHIP; }
+    HIPCHK(hipMemsetAsync(c->img, 0, nimg * 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  // width-20 Burgers nets take a fused path by default (2: f32 register-stash, 1: HBM-stash)
+  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : 0;
   *out = c;
   return 0;
 }
@@ -386,7 +417,7 @@ int pinn_destroy(pinn_ctx* c) {
                   c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
-                  c->lb_cy, c->lb_ex};
+                  c->lb_cy, c->lb_ex, c->img};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -503,9 +534,9 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
     int rc = eval_loss_grad(c);                   // reduce -> RCCL all-reduce -> update
     if (rc) return rc;
     if (c->dtype == PINN_F64)
-      hipLaunchKernelGGL((k_adam<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (double*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n);
+      hipLaunchKernelGGL((k_adam<double>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (double*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n, c->nd, c->img);
     else
-      hipLaunchKernelGGL((k_adam<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (float*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n);
+      hipLaunchKernelGGL((k_adam<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (float*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n, c->nd, c->img);
   }
   HIPCHK(hipGetLastError());
   if (losses) {
@@ -593,13 +624,13 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
       c->lb_post_pending = false;
       const dim3 agrid((n + 63) / 64);
       if (c->dtype == PINN_F64)
-        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r);
+        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r, c->nd, c->img);
       else
-        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r);
+        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r, c->nd, c->img);
     } else if (c->dtype == PINN_F64)
-      hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
+      hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     else
-      hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q);
+      hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
     int rc = eval_loss_grad(c);
     if (rc) return rc;
@@ -697,6 +728,10 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
   const int NO = c->nd.n_out;
   if ((size_t)cnt * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)cnt * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)cnt * NO; }
   const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
+  {  // the forward sweep below stashes one chunk of Taylor channels (the fused paths keep none)
+    const size_t need_S = (size_t)c->nd.n_hidden * c->nd.width * (size_t)c->chunk * 4 * real_size(c);
+    if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
+  }
   for (int base = 0; base < sd.n_pad; base += c->chunk) {
     const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
     if (c->dtype == PINN_F64)
@@ -775,9 +810,11 @@ int pinn_sync(pinn_ctx* c) {
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
-  REQUIRE(c && (path == 0 || path == 1), "path must be 0 (generic) or 1 (fused width-20)");
+  REQUIRE(c && path >= 0 && path <= 2, "path must be 0 (generic), 1 (fused width-20) or 2 (fused width-20, register stash)");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");
+  if (path == 2)
+    REQUIRE(fused_regs_ok(c), "the register-stash path needs float32, hidden width 20, 8 hidden layers and a Burgers problem");
   c->path = path;
   c->sets_dirty = true;
   return 0;
@@ -786,11 +823,11 @@ int pinn_set_kernel_path(pinn_ctx* c, int path) {
 int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves) {
 #ifdef PINN_STAMPS
   REQUIRE(c && out && n_waves, "null");
-  REQUIRE(c->path == 1, "stamps exist for the fused kernel only");
+  REQUIRE(c->path >= 1, "stamps exist for the fused kernels only");
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_sets(c);
   if (rc) return rc;
-  const size_t n = (size_t)c->sd.n_pad / 64 * 4 * 32;
+  const size_t n = (size_t)(c->path == 2 ? c->n_wg : c->sd.n_pad / 64) * 4 * 32;
   REQUIRE((size_t)cap >= n, "stamp buffer too small: need %zu", n);
   if (dev_alloc(&c->stamps, n * 8)) return PINN_EHIP;
   HIPCHK(hipMemsetAsync(c->stamps, 0, n * 8, c->stream));

@@ -3,7 +3,7 @@
 // float64 end to end, utils/neuralnetwork.py:24-26); the compute kernels read a `real`
 // mirror of the weights that these kernels keep in sync.
 #pragma once
-#include "wave.h"
+#include "kernels_fused20r.h"
 
 namespace pinn {
 
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_reduce_adam(const real* __restrict__ pa
                                                      real* __restrict__ theta_r,
                                                      double* __restrict__ m, double* __restrict__ v,
                                                      double alpha, double b1, double b2, double eps,
-                                                     double* __restrict__ loss3) {
+                                                     double* __restrict__ loss3, NetDesc nd,
+                                                     float* __restrict__ img) {
   __shared__ double sh[4][RED_COLS];
   const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const double g = reduce_column(part, n_rows, R, c, q, sh);
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(const real* __restrict__ pa
     const double t = theta[c] - alpha * mi / (sqrt(vi) + eps);
     theta[c] = t;
     theta_r[c] = (real)t;
+    pack_store(nd, img, c, (float)t);
   } else if (loss3 && c < n + 3) {
     loss3[c - n] = g;
   }
@@ -79,7 +81,8 @@ template <typename real>
 __global__ void k_adam(int n, const double* __restrict__ gl, double* __restrict__ theta,
                        real* __restrict__ theta_r, double* __restrict__ m,
                        double* __restrict__ v, double alpha, double b1, double b2, double eps,
-                       double* __restrict__ loss3, int n_theta) {
+                       double* __restrict__ loss3, int n_theta, NetDesc nd,
+                       float* __restrict__ img) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 3 && loss3) loss3[i] = gl[n_theta + i];
   if (i >= n) return;
@@ -91,12 +94,14 @@ __global__ void k_adam(int n, const double* __restrict__ gl, double* __restrict_
   const double t = theta[i] - alpha * mi / (sqrt(vi) + eps);
   theta[i] = t;
   theta_r[i] = (real)t;
+  pack_store(nd, img, i, (float)t);
 }
 
 template <typename real>
-__global__ void k_cast_weights(int n, const double* __restrict__ theta, real* __restrict__ theta_r) {
+__global__ void k_cast_weights(int n, const double* __restrict__ theta, real* __restrict__ theta_r,
+                               NetDesc nd, float* __restrict__ img) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) theta_r[i] = (real)theta[i];
+  if (i < n) { theta_r[i] = (real)theta[i]; pack_store(nd, img, i, (float)theta[i]); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
     const double* __restrict__ g, double* __restrict__ x, double* __restrict__ theta,
     real* __restrict__ theta_r, double* __restrict__ d, double* __restrict__ g_old,
     double* __restrict__ Sh, double* __restrict__ Yh, double* __restrict__ ro,
-    double* __restrict__ al, double* __restrict__ q) {
+    double* __restrict__ al, double* __restrict__ q, NetDesc nd, float* __restrict__ img) {
   __shared__ double sh[LB_THREADS / 64];
   __shared__ int s_flag;
   if (st->done) return;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
   for (int i = tid; i < n; i += LB_THREADS) {
     const double xi = x[i] + t * d[i];                 // :174
     x[i] = xi;
-    if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; }
+    if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store(nd, img, i, (float)xi); }
   }
   if (tid == 0) {
     st->n_iter = n_iter; st->hist_len = hist_len; st->hist_head = head; st->Hdiag = Hdiag;
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(256) void k_lbc_apply(
     const double* __restrict__ g, const double* __restrict__ Sh, const double* __restrict__ Yh,
     const double* __restrict__ cs, const double* __restrict__ cy, double* __restrict__ d,
     double* __restrict__ g_old, double* __restrict__ x, double* __restrict__ theta,
-    real* __restrict__ theta_r) {
+    real* __restrict__ theta_r, NetDesc nd, float* __restrict__ img) {
   __shared__ double sh[4][64];
   if (!ex->apply) return;
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void k_lbc_apply(
   g_old[i] = gi;
   const double xi = x[i] + st->t * di;
   x[i] = xi;
-  if (ex->will_eval) { theta[i] = xi; theta_r[i] = (real)xi; }
+  if (ex->will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store(nd, img, i, (float)xi); }
 }
 
 }  // namespace pinn

@@ -40,7 +40,7 @@ def make_burgers(sets, N_u, N_f, dtype, path=None):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("path", [0, 1])
+@pytest.mark.parametrize("path", [0, 1, 2])
 @pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
 def test_burgers_eval_vs_golden_and_oracle(burgers_sets, dtype, path, tag, N_u, N_f):
     from oracle import pde
@@ -64,6 +64,29 @@ def test_burgers_eval_vs_golden_and_oracle(burgers_sets, dtype, path, tag, N_u, 
     assert rel(grad, go) < tol["grad"]
     f = eng.residual()
     assert rel(f, ex["f"]) < tol["grad"] * 10
+    eng.close()
+
+
+@pytest.mark.parametrize("N_f", [40000, 100001])
+def test_burgers_persistent_tiles_f32(burgers_sets, N_f):
+    """more 64-point tiles than compute units: the register-stash kernel (path 2) loops over tiles
+    inside a workgroup and must agree with the oracle and with the generic kernels (path 0)"""
+    from oracle import pde
+    g = np.load(golden("burgers_eval.npz"))
+    eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, 100, N_f, "f32", 2)
+    rs = np.random.RandomState(11)
+    w1 = g["w0"] + 0.05 * rs.standard_normal(g["w0"].size)
+    eng.set_weights(w1)
+    loss, grad, _ = eng.loss_grad()
+    lo, go, _ = pde.burgers_loss_grad(w1, layers, lb, ub, X_f, X_u, u, NU)
+    assert abs(loss - lo) / lo < TOL["f32"]["loss"]
+    assert rel(grad, go) < TOL["f32"]["grad"]
+    loss_b, grad_b, _ = eng.loss_grad()                  # bit-reproducible run to run
+    assert loss_b == loss and np.array_equal(grad_b, grad)
+    eng.set_kernel_path(0)
+    loss0, grad0, _ = eng.loss_grad()
+    assert abs(loss - loss0) / loss0 < TOL["f32"]["loss"]
+    assert rel(grad, grad0) < TOL["f32"]["grad"]
     eng.close()
 
 
