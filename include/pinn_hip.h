@@ -128,6 +128,8 @@ int pinn_get_kernel_path(pinn_ctx* c, int* path);
 /* Profiling build (-DPINN_STAMPS) only: one evaluation with a per-wave s_memtime timeline of the
  * fused kernel; out[wave][32] ticks, n_waves = 4 x workgroups.  PINN_EUNSUPPORTED otherwise. */
 int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves);
+/* Profiling build only: s_memtime stamps of the most recent k_lbc_coef launch (7 used of 16). */
+int pinn_debug_coef_stamps(long long* out16);
 
 #ifdef __cplusplus
 }

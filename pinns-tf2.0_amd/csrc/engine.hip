@@ -284,11 +284,11 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const int n_rows = c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
   const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
   if (af)
-    hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
+    hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
                        c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img);
   else
-    hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(256), 0, c->stream, (const real*)c->part,
+    hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl);
   HIPCHK(hipGetLastError());
   return 0;
@@ -567,7 +567,10 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   const int M1 = n_corr + 1;                                       // ring slots (compact mode)
   c->lb_M1 = M1;
   // compact mode needs the two padded Gram matrices in LDS (<= 64 KiB) and one lane per slot
-  c->lb_mode_active = (c->lb_mode == 1 && M1 <= 62) ? 1 : 0;
+  c->lb_mode_active = (c->lb_mode == 1 && M1 <= LBC_MAXSLOTS) ? 1 : 0;
+  if (c->lb_mode_active && lbc_coef_lds_bytes(M1) > 64 * 1024)
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lbc_coef_lds_bytes(M1)));
   if (n_corr > c->lb_cap_corr) {
     if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
         dev_alloc(&c->lb_ro, (size_t)M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
@@ -577,6 +580,10 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
       return PINN_EHIP;
     c->lb_cap_corr = n_corr;
   }
+  HIPCHK(hipMemsetAsync(c->lb_S, 0, (size_t)M1 * n * 8, c->stream));   // unused ring slots must read as finite
+  HIPCHK(hipMemsetAsync(c->lb_Y, 0, (size_t)M1 * n * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_cs, 0, (size_t)M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_cy, 0, (size_t)M1 * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)M1 * M1 * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)M1 * M1 * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + LBC_NSCAL) * 8, c->stream));
@@ -613,8 +620,8 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     c->lb_iters_issued += 1;
     if (c->lb_mode_active) {
       const int M1 = c->lb_M1;
-      const size_t lsh = (size_t)2 * M1 * lbc_ld(M1) * 8;
-      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBC_THREADS), 0, c->stream, n, M1, c->lb_state,
+      const size_t lsh = lbc_coef_lds_bytes(M1);
+      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, c->lb_state,
                          c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
       hipLaunchKernelGGL(k_lbc_coef, dim3(1), dim3(LBC_THREADS), lsh, c->stream, M1, c->lb_ncorr,
                          c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun, c->lb_max_eval,
@@ -624,9 +631,9 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
       c->lb_post_pending = false;
       const dim3 agrid((n + 63) / 64);
       if (c->dtype == PINN_F64)
-        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r, c->nd, c->img);
+        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(64 * LBA_SLICES), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r, c->nd, c->img);
       else
-        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(256), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r, c->nd, c->img);
+        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(64 * LBA_SLICES), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r, c->nd, c->img);
     } else if (c->dtype == PINN_F64)
       hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     else
@@ -841,6 +848,18 @@ int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves
   return 0;
 #else
   (void)c; (void)out; (void)cap; (void)n_waves;
+  return fail(PINN_EUNSUPPORTED, "built without -DPINN_STAMPS (profiling build only)");
+#endif
+}
+
+int pinn_debug_coef_stamps(long long* out16) {
+#ifdef PINN_STAMPS
+  REQUIRE(out16, "null");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coef_stamps), 16 * sizeof(long long)));
+  return 0;
+#else
+  (void)out16;
   return fail(PINN_EUNSUPPORTED, "built without -DPINN_STAMPS (profiling build only)");
 #endif
 }

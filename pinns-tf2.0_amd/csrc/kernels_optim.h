@@ -9,10 +9,12 @@ namespace pinn {
 
 // gl[c] = sum over rows of part[row*R + c] in a fixed order (bit-reproducible).
 // gl layout: [0, n_theta) gradient | n_theta+0..2 loss parts (residual, data, boundary).
-// Block = 64 columns x 4 row-quarters (row r belongs to quarter r & 3); each thread keeps 8
-// independent accumulators so that 8 loads are in flight, then the quarters are combined
-// through LDS in index order.  Grid = ceil(R / 64) blocks of 256 threads.
+// Block = 64 columns x 16 row-slices (row r belongs to slice r & 15): 1024 threads, each with up to
+// 8 independent loads in flight; the slices are combined through LDS in index order.
+// Grid = ceil(R / 64) blocks.
 constexpr int RED_COLS = 64;
+constexpr int RED_SLICES = 16;
+constexpr int RED_THREADS = RED_COLS * RED_SLICES;
 
 template <typename real>
 __device__ __forceinline__ double reduce_column(const real* __restrict__ part, int n_rows, int R,
@@ -22,23 +24,34 @@ __device__ __forceinline__ double reduce_column(const real* __restrict__ part, i
   if (c < R) {
     const real* __restrict__ p = part + c;
     int r = q;
-    for (; r + 28 < n_rows; r += 32) {
-      a0 += (double)p[(size_t)(r + 0) * R];  a1 += (double)p[(size_t)(r + 4) * R];
-      a2 += (double)p[(size_t)(r + 8) * R];  a3 += (double)p[(size_t)(r + 12) * R];
-      a4 += (double)p[(size_t)(r + 16) * R]; a5 += (double)p[(size_t)(r + 20) * R];
-      a6 += (double)p[(size_t)(r + 24) * R]; a7 += (double)p[(size_t)(r + 28) * R];
+    for (; r + 7 * RED_SLICES < n_rows; r += 8 * RED_SLICES) {
+      a0 += (double)p[(size_t)(r + 0 * RED_SLICES) * R]; a1 += (double)p[(size_t)(r + 1 * RED_SLICES) * R];
+      a2 += (double)p[(size_t)(r + 2 * RED_SLICES) * R]; a3 += (double)p[(size_t)(r + 3 * RED_SLICES) * R];
+      a4 += (double)p[(size_t)(r + 4 * RED_SLICES) * R]; a5 += (double)p[(size_t)(r + 5 * RED_SLICES) * R];
+      a6 += (double)p[(size_t)(r + 6 * RED_SLICES) * R]; a7 += (double)p[(size_t)(r + 7 * RED_SLICES) * R];
     }
-    for (; r < n_rows; r += 4) a0 += (double)p[(size_t)r * R];
+    if (r < n_rows) a0 += (double)p[(size_t)r * R];
+    if (r + 1 * RED_SLICES < n_rows) a1 += (double)p[(size_t)(r + 1 * RED_SLICES) * R];
+    if (r + 2 * RED_SLICES < n_rows) a2 += (double)p[(size_t)(r + 2 * RED_SLICES) * R];
+    if (r + 3 * RED_SLICES < n_rows) a3 += (double)p[(size_t)(r + 3 * RED_SLICES) * R];
+    if (r + 4 * RED_SLICES < n_rows) a4 += (double)p[(size_t)(r + 4 * RED_SLICES) * R];
+    if (r + 5 * RED_SLICES < n_rows) a5 += (double)p[(size_t)(r + 5 * RED_SLICES) * R];
+    if (r + 6 * RED_SLICES < n_rows) a6 += (double)p[(size_t)(r + 6 * RED_SLICES) * R];
   }
   sh[q][cl] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   __syncthreads();
-  return (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+  double tot = 0;
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < RED_SLICES; ++i) tot += sh[i][cl];
+  }
+  return tot;
 }
 
 template <typename real>
-__global__ __launch_bounds__(256) void k_reduce_rows(const real* __restrict__ part, int n_rows,
-                                                     int R, double* __restrict__ gl) {
-  __shared__ double sh[4][RED_COLS];
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const real* __restrict__ part, int n_rows,
+                                                             int R, double* __restrict__ gl) {
+  __shared__ double sh[RED_SLICES][RED_COLS];
   const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const double g = reduce_column(part, n_rows, R, c, q, sh);
   if (q == 0 && c < R) gl[c] = g;
@@ -47,15 +60,15 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const real* __restrict__ pa
 // Single-GPU Adam step fused behind the reduction (no all-reduce in between): same arithmetic as
 // k_reduce_rows followed by k_adam.  loss3 (may be null) <- the three loss parts of this step.
 template <typename real>
-__global__ __launch_bounds__(256) void k_reduce_adam(const real* __restrict__ part, int n_rows,
-                                                     int R, double* __restrict__ gl, int n,
-                                                     double* __restrict__ theta,
-                                                     real* __restrict__ theta_r,
-                                                     double* __restrict__ m, double* __restrict__ v,
-                                                     double alpha, double b1, double b2, double eps,
-                                                     double* __restrict__ loss3, NetDesc nd,
-                                                     float* __restrict__ img) {
-  __shared__ double sh[4][RED_COLS];
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_adam(const real* __restrict__ part, int n_rows,
+                                                             int R, double* __restrict__ gl, int n,
+                                                             double* __restrict__ theta,
+                                                             real* __restrict__ theta_r,
+                                                             double* __restrict__ m, double* __restrict__ v,
+                                                             double alpha, double b1, double b2, double eps,
+                                                             double* __restrict__ loss3, NetDesc nd,
+                                                             float* __restrict__ img) {
+  __shared__ double sh[RED_SLICES][RED_COLS];
   const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const double g = reduce_column(part, n_rows, R, c, q, sh);
   if (q != 0 || c >= R) return;
@@ -302,70 +315,125 @@ struct LbcExtra {
   double cg, gtd;
 };
 
-constexpr int LBC_THREADS = 256;
+constexpr int LBC_THREADS = 1024;  // k_lbc_coef: 16 waves stage the Gram matrices, wave 0 runs the recursion
+constexpr int LBC_ROWS = 4;        // ceil(62 / 16) matrix rows per thread
+constexpr int LBD_THREADS = 1024;  // k_lbc_dots: n = 3021 is three strides of a 1024-thread block
 constexpr int LBC_NSCAL = 5;       // trailing scalars of the dots array
 
-__device__ __forceinline__ double block_sum256(double v, double* sh) {
-  const double w = wave_sum(v);
+// sums NV values over the block: DPP wave sums, one LDS exchange, wave totals added in index order
+template <int NV>
+__device__ __forceinline__ void block_sums(double (&v)[NV], double (*sh)[8]) {
+  const int w = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const double t = wave_sum(v[i]);
+    if ((threadIdx.x & 63) == 0) sh[w][i] = t;
+  }
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = w;
-  __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < LBD_THREADS / 64; ++k) t += sh[k][i];
+    v[i] = t;
+  }
 }
 
 // dots layout: [0,M1) s_a.y_c | [M1,2M1) s_c.y_a | [2M1,3M1) y_a.y_c | [3M1,4M1) s_a.g |
 //              [4M1,5M1) y_a.g | 5M1+0 y_c.s_c | +1 y_c.y_c | +2 g.g | +3 |g|_1 | +4 |t d|_1
-__global__ __launch_bounds__(LBC_THREADS) void k_lbc_dots(
+__global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
     int n, int M1, const LbfgsState* __restrict__ st, const double* __restrict__ g,
     const double* __restrict__ g_old, const double* __restrict__ d, double* __restrict__ Sh,
     double* __restrict__ Yh, double* __restrict__ dots) {
-  __shared__ double sh[4];
-  if (st->done) return;
-  const int head = st->hist_head, len = st->hist_len;
-  const bool first = (st->n_iter == 0);
-  int c = head + len; if (c >= M1) c -= M1;
-  const int a = blockIdx.x;
-  int pos = a - head; if (pos < 0) pos += M1;
+  __shared__ double sh[LBD_THREADS / 64][8];
+  constexpr int NS = 4;                           // strides of LBD_THREADS covered (n <= 4096 fast path)
+  const int a = blockIdx.x, tid = threadIdx.x;
+  // one round of global reads: state + this thread's slice of g, g_old, d and of history row a
+  const int done0 = st->done, head = st->hist_head, len = st->hist_len, n_it = st->n_iter;
   const double t = st->t;
-  const int tid = threadIdx.x;
+  double gv[NS], gov[NS], dv[NS], sav[NS], yav[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    const int i = tid + u * LBD_THREADS;
+    const bool ok = i < n;
+    gv[u] = ok ? g[i] : 0.0; gov[u] = ok ? g_old[i] : 0.0; dv[u] = ok ? d[i] : 0.0;
+    sav[u] = ok ? Sh[(size_t)a * n + i] : 0.0; yav[u] = ok ? Yh[(size_t)a * n + i] : 0.0;
+  }
+  if (done0) return;
+  const bool first = (n_it == 0);
+  int c = head + len; if (c >= M1) c -= M1;
+  int pos = a - head; if (pos < 0) pos += M1;
   if (a == c) {
-    double ys = 0, yy = 0, sg = 0, yg = 0, gg = 0, ga = 0, sa = 0;
-    for (int i = tid; i < n; i += LBC_THREADS) {
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};          // ys yy sg yg gg ga sa
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = tid + u * LBD_THREADS;
+      if (i < n) {
+        const double gi = gv[u];
+        v[4] += gi * gi; v[5] += fabs(gi);
+        if (!first) {
+          const double y = gi - gov[u], s = dv[u] * t;
+          Sh[(size_t)c * n + i] = s; Yh[(size_t)c * n + i] = y;
+          v[0] += y * s; v[1] += y * y; v[2] += s * gi; v[3] += y * gi; v[6] += fabs(s);
+        }
+      }
+    }
+    for (int i = tid + NS * LBD_THREADS; i < n; i += LBD_THREADS) {      // n > 4096: plain loop
       const double gi = g[i];
-      gg += gi * gi; ga += fabs(gi);
+      v[4] += gi * gi; v[5] += fabs(gi);
       if (!first) {
         const double y = gi - g_old[i], s = d[i] * t;
         Sh[(size_t)c * n + i] = s; Yh[(size_t)c * n + i] = y;
-        ys += y * s; yy += y * y; sg += s * gi; yg += y * gi; sa += fabs(s);
+        v[0] += y * s; v[1] += y * y; v[2] += s * gi; v[3] += y * gi; v[6] += fabs(s);
       }
     }
-    ys = block_sum256(ys, sh); yy = block_sum256(yy, sh); sg = block_sum256(sg, sh);
-    yg = block_sum256(yg, sh); gg = block_sum256(gg, sh); ga = block_sum256(ga, sh);
-    sa = block_sum256(sa, sh);
+    block_sums(v, sh);
     if (tid == 0) {
-      dots[5 * M1 + 0] = ys; dots[5 * M1 + 1] = yy; dots[5 * M1 + 2] = gg; dots[5 * M1 + 3] = ga;
-      dots[5 * M1 + 4] = sa;
-      dots[3 * M1 + c] = sg; dots[4 * M1 + c] = yg;
+      dots[5 * M1 + 0] = v[0]; dots[5 * M1 + 1] = v[1]; dots[5 * M1 + 2] = v[4]; dots[5 * M1 + 3] = v[5];
+      dots[5 * M1 + 4] = v[6];
+      dots[3 * M1 + c] = v[2]; dots[4 * M1 + c] = v[3];
     }
   } else if (pos < len) {
-    double say = 0, sya = 0, yya = 0, sg = 0, yg = 0;
-    for (int i = tid; i < n; i += LBC_THREADS) {
+    double v[5] = {0, 0, 0, 0, 0};                // say sya yya sg yg
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const double gi = gv[u], sa = sav[u], ya = yav[u];
+      const double yc = gi - gov[u], sc = dv[u] * t;
+      v[0] += sa * yc; v[1] += sc * ya; v[2] += ya * yc; v[3] += sa * gi; v[4] += ya * gi;
+    }
+    for (int i = tid + NS * LBD_THREADS; i < n; i += LBD_THREADS) {
       const double gi = g[i], sa = Sh[(size_t)a * n + i], ya = Yh[(size_t)a * n + i];
       const double yc = gi - g_old[i], sc = d[i] * t;
-      say += sa * yc; sya += sc * ya; yya += ya * yc; sg += sa * gi; yg += ya * gi;
+      v[0] += sa * yc; v[1] += sc * ya; v[2] += ya * yc; v[3] += sa * gi; v[4] += ya * gi;
     }
-    say = block_sum256(say, sh); sya = block_sum256(sya, sh); yya = block_sum256(yya, sh);
-    sg = block_sum256(sg, sh); yg = block_sum256(yg, sh);
+    block_sums(v, sh);
     if (tid == 0) {
-      dots[a] = say; dots[M1 + a] = sya; dots[2 * M1 + a] = yya;
-      dots[3 * M1 + a] = sg; dots[4 * M1 + a] = yg;
+      dots[a] = v[0]; dots[M1 + a] = v[1]; dots[2 * M1 + a] = v[2];
+      dots[3 * M1 + a] = v[3]; dots[4 * M1 + a] = v[4];
     }
   }
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-inline int lbc_ld(int M1) { return M1 | 1; }     // odd leading dimension: column walks hit distinct banks
 
+#ifdef PINN_STAMPS
+__device__ long long g_coef_stamps[16];         // s_memtime timeline of the last k_lbc_coef (profiling build)
+#define CSTAMP(i) do { if (threadIdx.x == 0) g_coef_stamps[i] = clock64(); } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+inline int lbc_ld(int M1) { return M1 | 1; }     // odd leading dimension: column walks hit distinct banks
+constexpr int LBC_MAXSLOTS = 62;                  // one lane per ring slot
+inline size_t lbc_coef_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64) * 8; }
+
+// The recursion runs in *position* space (p = 0 oldest pair ... len-1 newest; lane = position), on
+// three LDS matrices prepared while staging so that a recursion step is exactly
+// {broadcast, fma, fma} with immediate-offset operands and no select:
+//   sU[p][j] = ro_p (s_p.y_j) for j > p, else 0    backward: b_p -= al_j sU[p][j]; b_p is final (= al_p)
+//   sY[p][j] = y_p.y_j                              backward: y_p.q_0 -= al_j sY[p][j]
+//   sL[p][j] = ro_p (s_j.y_p) for j < p, else 0    forward:  e_p -= cs_j sL[p][j]; e_p is final (= cs_p)
+// (the zeros freeze a lane's value once its own step has passed).  Global reads stay in ring-slot
+// order (one round); the rotation by `head` happens in the LDS write addresses.
 __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
     int M1, int m, int max_iter, double lr, double tol_x, double tol_fun, double max_eval,
     int do_post, int n_theta, LbfgsState* __restrict__ st, LbcExtra* __restrict__ ex,
@@ -375,32 +443,44 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
   extern __shared__ double lsh[];
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
   const int LD = M1 | 1;
-  double* sSY = lsh;
-  double* sYY = lsh + M1 * LD;
-  if (st->done) { if (tid == 0) ex->apply = 0; return; }
-  // snapshot of the state (thread 0 writes it back after the barrier below)
+  double* const sU = lsh;
+  double* const sL = sU + M1 * LD;
+  double* const sY = sL + M1 * LD;
+  double* const sT = sY + M1 * LD;                 // 6 x 64 per-slot vectors: say sya yya sg yg ro
+  CSTAMP(0);
+  // ---- every global read of this kernel, issued as ONE round (a dependent round costs 1.5-2 us)
+  const bool in_row = lane < M1;
+  const int done0 = uni(st->done);
   const int n_iter_prev = uni(st->n_iter), fe_prev = uni(st->func_eval), n_logged = uni(st->n_logged);
   int head = uni(st->hist_head), len = uni(st->hist_len);
   double Hdiag = st->Hdiag, f_cur = st->f;
   const double f_old_prev = st->f_old;
   const double ys = dots[5 * M1 + 0], yy = dots[5 * M1 + 1];
   const double gg = dots[5 * M1 + 2], gabs = dots[5 * M1 + 3], sabs = dots[5 * M1 + 4];
+  const double d_say = in_row ? dots[lane] : 0.0, d_sya = in_row ? dots[M1 + lane] : 0.0;
+  const double d_yya = in_row ? dots[2 * M1 + lane] : 0.0;
+  const double d_sg = in_row ? dots[3 * M1 + lane] : 0.0, d_yg = in_row ? dots[4 * M1 + lane] : 0.0;
+  const double ro_l0 = in_row ? ro[lane] : 0.0;
+  const double f_new = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
+  double ra[LBC_ROWS], rb[LBC_ROWS];
+#pragma unroll
+  for (int u = 0; u < LBC_ROWS; ++u) {
+    const int r = wave + 16 * u;
+    const bool ok = r < M1 && in_row;
+    ra[u] = ok ? SY[r * M1 + lane] : 0.0;
+    rb[u] = ok ? YY[r * M1 + lane] : 0.0;
+  }
+  if (done0) { if (tid == 0) ex->apply = 0; return; }
+  CSTAMP(1);
   int dn = 0;
   if (do_post) {                                   // custom_lbfgs.py:185-215 for the last evaluation
-    f_cur = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
+    f_cur = f_new;
     if (n_iter_prev == max_iter) dn = 1;
     else if ((double)(fe_prev + 1) >= max_eval) dn = 3;
     else if (gabs <= tol_fun) dn = 4;
     else if (sabs <= tol_x) dn = 5;
     else if (fabs(f_cur - f_old_prev) < tol_x) dn = 6;
   }
-  for (int r = wave; r < M1; r += 4) {
-    if (lane < M1) {
-      sSY[r * LD + lane] = SY[r * M1 + lane];
-      sYY[r * LD + lane] = YY[r * M1 + lane];
-    }
-  }
-  __syncthreads();
   if (do_post && tid == 0) {
     st->f = f_cur; st->func_eval = fe_prev + 1;
     if (dn) { st->done = dn; ex->apply = 0; ex->will_eval = 0; }
@@ -416,53 +496,116 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
   int c = head + len; if (c >= M1) c -= M1;
   const bool accept = !first && ys > 1e-10;        // custom_lbfgs.py:102-114
   if (accept) {
-    if (wave == 0 && lane < M1) {
-      const double sya = (lane == c) ? ys : dots[M1 + lane];       // s_c . y_lane
-      const double say = (lane == c) ? ys : dots[lane];            // s_lane . y_c
-      const double yya = (lane == c) ? yy : dots[2 * M1 + lane];
-      sSY[c * LD + lane] = sya; SY[c * M1 + lane] = sya;
-      sSY[lane * LD + c] = say; SY[lane * M1 + c] = say;
-      sYY[c * LD + lane] = yya; YY[c * M1 + lane] = yya;
-      sYY[lane * LD + c] = yya; YY[lane * M1 + c] = yya;
-    }
-    if (tid == 0) ro[c] = 1.0 / ys;
     Hdiag = ys / yy;
     if (len == m) { head += 1; if (head >= M1) head -= M1; } else len += 1;
   }
-  __syncthreads();
+  const double ro_l = (accept && lane == c) ? 1.0 / ys : ro_l0;
+  if (wave == 0) {                                 // per-slot vectors for everybody
+    sT[0 * 64 + lane] = d_say; sT[1 * 64 + lane] = d_sya; sT[2 * 64 + lane] = d_yya;
+    sT[3 * 64 + lane] = d_sg;  sT[4 * 64 + lane] = d_yg;  sT[5 * 64 + lane] = ro_l;
+    if (accept && lane == c) ro[c] = ro_l;
+  }
+  lds_barrier();     // LDS-only: must not wait for the global stores above
+  CSTAMP(2);
+  {  // patch the candidate row/column, scale, mask, rotate, stage (branch-free per row)
+    int pb = lane - head; if (pb < 0) pb += M1;
+    const bool vb = in_row && pb < len;
+    const bool lc = accept && lane == c;
+    const int col = in_row ? lane : 0;
+    double ro_r[LBC_ROWS], say_r[LBC_ROWS], yya_r[LBC_ROWS];   // LDS reads before LDS writes
+#pragma unroll
+    for (int u = 0; u < LBC_ROWS; ++u) {
+      const int r = wave + 16 * u, rr = r < M1 ? r : 0;
+      ro_r[u] = sT[5 * 64 + rr]; say_r[u] = sT[0 * 64 + rr]; yya_r[u] = sT[2 * 64 + rr];
+    }
+#pragma unroll
+    for (int u = 0; u < LBC_ROWS; ++u) {
+      const int r = wave + 16 * u;                  // wave-uniform
+      if (r < M1) {
+        const bool rc = accept && r == c;
+        const double sy = rc ? (lc ? ys : d_sya) : (lc ? say_r[u] : ra[u]);   // s_c.y_l | s_r.y_c | stored
+        const double y2 = rc ? (lc ? yy : d_yya) : (lc ? yya_r[u] : rb[u]);
+        int pa = r - head; if (pa < 0) pa += M1;
+        const bool both = vb && pa < len;
+        const double vu = (both && pb > pa) ? ro_r[u] * sy : 0.0;
+        const double vy = both ? y2 : 0.0;
+        const double vl = (both && pa < pb) ? ro_l * sy : 0.0;
+        if (in_row) { sU[pa * LD + pb] = vu; sY[pa * LD + pb] = vy; sL[pb * LD + pa] = vl; }
+        (void)col;
+      }
+    }
+    if (accept && wave == 0 && in_row) {            // persist the accepted pair's row and column
+      const double sya = (lane == c) ? ys : d_sya, say = (lane == c) ? ys : d_say;
+      const double yya = (lane == c) ? yy : d_yya;
+      SY[c * M1 + lane] = sya; SY[lane * M1 + c] = say;
+      YY[c * M1 + lane] = yya; YY[lane * M1 + c] = yya;
+    }
+  }
+  lds_barrier();     // LDS-only: must not wait for the global stores above
   if (wave != 0) return;
+  CSTAMP(3);
 
-  int my_pos = lane - head; if (my_pos < 0) my_pos += M1;
-  const bool my_in = lane < M1 && my_pos < len;
-  const double my_sg = my_in ? dots[3 * M1 + lane] : 0.0;
-  const double my_yg = my_in ? dots[4 * M1 + lane] : 0.0;
-  double my_ro = 0.0;
-  if (my_in) my_ro = (accept && lane == c) ? 1.0 / ys : ro[lane];
-  const int row = (my_in ? lane : 0) * LD;
+  // lane = position p
+  int slot = lane + head; if (slot >= M1) slot -= M1;
+  const bool valid = lane < len;
+  const int sidx = in_row ? slot : 0;
+  const double sg_p = valid ? sT[3 * 64 + sidx] : 0.0, yg_p = valid ? sT[4 * 64 + sidx] : 0.0;
+  const double ro_p = valid ? sT[5 * 64 + sidx] : 0.0;
+  const double* __restrict__ rowU = sU + (in_row ? lane : 0) * LD;
+  const double* __restrict__ rowY = sY + (in_row ? lane : 0) * LD;
+  const double* __restrict__ rowL = sL + (in_row ? lane : 0) * LD;
 
-  // backward loop: al_i = ro_i * s_i.q_i, q_i = -g - sum_{j>i} al_j y_j.  Lane a carries
-  // acc = sum_{j done} al_j (s_a.y_j); yq0 accumulates y_a.q_0 on the way.
-  double acc = 0.0, yq0 = -my_yg, al = 0.0;
-  for (int i = len - 1; i >= 0; --i) {
-    int si = head + i; if (si >= M1) si -= M1;
-    const double al_i = read_lane(my_ro * (-my_sg - acc), si);
-    if (lane == si) al = al_i;
-    acc += al_i * sSY[row + si];
-    yq0 -= al_i * sYY[row + si];
+  // Both loops run in chunks of 8 steps: a chunk is straight-line code (its 8-16 LDS operands are
+  // fetched together, ahead of the dependent broadcast->fma chain) and is skipped as a whole when
+  // it lies beyond len.  Steps in [len, M1) inside the last chunk are harmless: their lanes hold
+  // exact zeros and their matrix columns are zero.
+  // backward loop (custom_lbfgs.py:130-133): al_i = ro_i s_i.q_i, q_i = -g - sum_{j>i} al_j y_j
+  double bacc = ro_p * -sg_p, yq0 = -yg_p;
+#pragma unroll
+  for (int c8 = (LBC_MAXSLOTS + 7) / 8 - 1; c8 >= 0; --c8) {
+    if (8 * c8 < len) {
+      double uu[8], yv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = 8 * c8 + k, ic = i < M1 ? i : M1 - 1;
+        uu[k] = rowU[ic]; yv[k] = rowY[ic];
+      }
+#pragma unroll
+      for (int k = 7; k >= 0; --k) {
+        const int i = 8 * c8 + k;
+        const double al_i = (i < M1) ? read_lane(bacc, i) : 0.0;
+        bacc -= al_i * uu[k];
+        yq0 -= al_i * yv[k];
+      }
+    }
   }
-  // forward loop: be_i = ro_i * y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j), cs_i = al_i - be_i.
-  // Lane a carries acc2 = sum_{j done} cs_j (s_j.y_a).
-  double acc2 = 0.0, cs = 0.0;
-  for (int i = 0; i < len; ++i) {
-    int si = head + i; if (si >= M1) si -= M1;
-    const double c_i = read_lane(al - my_ro * (Hdiag * yq0 + acc2), si);
-    if (lane == si) cs = c_i;
-    acc2 += c_i * sSY[si * LD + (my_in ? lane : 0)];
+  const double al = bacc;
+  CSTAMP(4);
+  // forward loop (:136-139): be_i = ro_i y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j), cs_i = al_i - be_i
+  double eacc = al - ro_p * (Hdiag * yq0);
+#pragma unroll
+  for (int c8 = 0; c8 < (LBC_MAXSLOTS + 7) / 8; ++c8) {
+    if (8 * c8 < len) {
+      double lv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = 8 * c8 + k, ic = i < M1 ? i : M1 - 1;
+        lv[k] = rowL[ic];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = 8 * c8 + k;
+        const double c_i = (i < M1) ? read_lane(eacc, i) : 0.0;
+        eacc -= c_i * lv[k];
+      }
+    }
   }
+  CSTAMP(5);
+  const double cs = eacc;
   const double cy = -Hdiag * al;
   const double cg = -Hdiag;
-  const double gtd = cg * gg + wave_sum(my_in ? (cy * my_yg + cs * my_sg) : 0.0);
-  if (lane < M1) { cs_out[lane] = my_in ? cs : 0.0; cy_out[lane] = my_in ? cy : 0.0; }
+  const double gtd = cg * gg + wave_sum(valid ? (cy * yg_p + cs * sg_p) : 0.0);
+  if (in_row) { cs_out[slot] = valid ? cs : 0.0; cy_out[slot] = valid ? cy : 0.0; }
   if (lane == 0) {
     st->n_iter = n_iter; st->hist_len = len; st->hist_head = head; st->Hdiag = Hdiag;
     st->f_old = f_cur;
@@ -478,46 +621,47 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
       if (n_iter == max_iter) st->done = 1;      // :192
     }
   }
+  CSTAMP(6);
 }
 
-// d = cg g + sum_j (cy_j y_j + cs_j s_j); g_old = g; x += t d.  Block = 64 elements x 4
-// history-quarters, combined through LDS in a fixed order.
+// d = cg g + sum_j (cy_j y_j + cs_j s_j); g_old = g; x += t d.  Block = 64 elements x 16 slices
+// of the history ring (1024 threads), combined through LDS in a fixed order.  The sum runs over
+// ring *slots*: k_lbc_coef writes zero coefficients for slots not in use (and the ring is zeroed
+// at begin), so nothing here depends on head/len and every global read is issued in one round.
+constexpr int LBA_SLICES = 16;
 template <typename real>
-__global__ __launch_bounds__(256) void k_lbc_apply(
+__global__ __launch_bounds__(64 * LBA_SLICES) void k_lbc_apply(
     int n, int M1, const LbfgsState* __restrict__ st, const LbcExtra* __restrict__ ex,
     const double* __restrict__ g, const double* __restrict__ Sh, const double* __restrict__ Yh,
     const double* __restrict__ cs, const double* __restrict__ cy, double* __restrict__ d,
     double* __restrict__ g_old, double* __restrict__ x, double* __restrict__ theta,
     real* __restrict__ theta_r, NetDesc nd, float* __restrict__ img) {
-  __shared__ double sh[4][64];
-  if (!ex->apply) return;
+  __shared__ double sh[LBA_SLICES][64];
   const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + cl;
-  const int head = st->hist_head, len = st->hist_len;
-  double p0 = 0.0, p1 = 0.0;
-  if (i < n) {
-    int p = q;
-    for (; p + 4 < len; p += 8) {
-      int s0 = head + p; if (s0 >= M1) s0 -= M1;
-      int s1 = head + p + 4; if (s1 >= M1) s1 -= M1;
-      p0 += cy[s0] * Yh[(size_t)s0 * n + i] + cs[s0] * Sh[(size_t)s0 * n + i];
-      p1 += cy[s1] * Yh[(size_t)s1 * n + i] + cs[s1] * Sh[(size_t)s1 * n + i];
-    }
-    for (; p < len; p += 4) {
-      int s0 = head + p; if (s0 >= M1) s0 -= M1;
-      p0 += cy[s0] * Yh[(size_t)s0 * n + i] + cs[s0] * Sh[(size_t)s0 * n + i];
-    }
+  const bool ok = i < n;
+  const int apply = ex->apply, will_eval = ex->will_eval;
+  const double cg = ex->cg, t = st->t;
+  const double gi = (ok && q == 0) ? g[i] : 0.0, xi0 = (ok && q == 0) ? x[i] : 0.0;
+  double p[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {                    // slots q, q+16, q+32, q+48 (M1 <= 62)
+    const int sl = q + 16 * u;
+    p[u] = (ok && sl < M1) ? cy[sl] * Yh[(size_t)sl * n + i] + cs[sl] * Sh[(size_t)sl * n + i] : 0.0;
   }
-  sh[q][cl] = p0 + p1;
+  if (!apply) return;
+  sh[q][cl] = (p[0] + p[1]) + (p[2] + p[3]);
   __syncthreads();
-  if (q != 0 || i >= n) return;
-  const double gi = g[i];
-  const double di = ex->cg * gi + ((sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]));
+  if (q != 0 || !ok) return;
+  double hist = 0.0;
+#pragma unroll
+  for (int k = 0; k < LBA_SLICES; ++k) hist += sh[k][cl];
+  const double di = cg * gi + hist;
   d[i] = di;
   g_old[i] = gi;
-  const double xi = x[i] + st->t * di;
+  const double xi = xi0 + t * di;
   x[i] = xi;
-  if (ex->will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store(nd, img, i, (float)xi); }
+  if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store(nd, img, i, (float)xi); }
 }
 
 }  // namespace pinn
