@@ -15,6 +15,7 @@
 #include "../../include/pinn_hip.h"
 #include "kernels_fused20.h"
 #include "kernels_fused20r.h"
+#include "kernels_fused20m.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
 
@@ -141,7 +142,7 @@ static bool fused_ok(const pinn_ctx* c) {
 // the register-stash kernel: float32, width 20, instantiated depths, weights + tiles within LDS
 static bool fused_regs_ok(const pinn_ctx* c) {
   return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER &&
-         c->nd.n_hidden == 8 && fused20r_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
+         c->nd.n_hidden == 8 && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
 }
 
 template <typename T>
@@ -250,11 +251,11 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2)
-      rc = fused20r_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+      rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
                                    (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
                                    (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
                                    c->stream, c->stamps);
-    if (rc) return fail(PINN_EHIP, "fused20r launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (rc) return fail(PINN_EHIP, "fused20m launch failed: %s", hipGetErrorString((hipError_t)rc));
     if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
   } else if (c->path == 1) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
@@ -397,7 +398,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
       c->n_cu = prop.multiProcessorCount;
   }
   if (fused_regs_ok(c)) {
-    const size_t nimg = fused20r_image_floats(nd.n_hidden);
+    const size_t nimg = fused20m_image_floats(nd.n_hidden);
     if (dev_alloc(&c->img, nimg * 4)) { delete c; return PINN_EHIP; }
     HIPCHK(hipMemsetAsync(c->img, 0, nimg * 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1,0 +1,398 @@
+// kernels_fused20m.h -- float32 loss+gradient kernel for width-20 tanh MLPs, every contraction on
+// the matrix instructions (k_fused20m).  Successor of k_fused20r (kernels_fused20r.h): same
+// workgroup (4 waves, lane = point, 64-point tiles, persistent), same register (AGPR) stash, same
+// 16x16x4 weight-gradient tiles; what changes is the layer GEMVs.
+//
+// Measured on gfx950 (profiles/r01_ubench_*.txt): a lone wave per SIMD issues one instruction per
+// ~5.3 cycles, and v_mfma_f32_* shares the FP32 datapath with the vector ALU (an MFMA and packed
+// FMAs never overlap).  A packed FMA retires 128 MACs per issue slot and needs its weight in an
+// SGPR (one v_readlane per weight); v_mfma_f32_4x4x1_16B_f32 retires 256 MACs per slot at the full
+// 32 MAC/clk/SIMD and takes the weights as a VGPR *pattern*: 16 blocks of 4 lanes, block b
+//   D_b[i][j] += A_b[i] * B_b[j],   A: lane 4b+i,  B: lane 4b+j,  D: VGPR i of lane 4b+j.
+// With lane = point, B is simply the input-feature register in_c[k], A is the register holding
+// W[k][f0 + lane%4] (period-4 pattern, one ds_read_b128 delivers four k at once), and D's four
+// VGPRs are out_c[f0..f0+3] of the same point: lane = point in, lane = point out, no padding
+// at 4-feature granularity (20 = 5 groups), no readlane, no splat.
+//
+// Ownership: wave w owns features {4w..4w+3} (group w: all four Taylor channels, 80 MFMAs per layer
+// and direction) plus feature 16+w.  Group 4 (features 16..19) is computed one *channel* per wave
+// (20 MFMAs), the four channels meet in a 4-row LDS scratch (Q) and wave w picks feature 16+w up
+// from there: 100 MFMAs = 826 cycles per wave, layer and direction, against ~2100 cycles for
+// the packed-FMA form.
+//
+// LDS weight image (floats), per hidden dense layer d = 1..H-1, WIMG = 820:
+//   [0,400)   W_d^T : [j][k]  forward patterns   (lane reads [(f0 + lane%4)*20 + 4m .. +3])
+//   [400,800) W_d   : [k][j]  reverse patterns
+//   [800,820) b_d
+//
+// Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
+// the outer tape of utils/neuralnetwork.py:55-59.
+#pragma once
+#include "kernels_fused20r.h"
+
+namespace pinn {
+
+constexpr int WIMG = 820;
+
+inline size_t fused20m_image_floats(int n_hidden) { return (size_t)(n_hidden - 1) * WIMG; }
+inline size_t fused20m_lds_bytes(int n_hidden) {
+  return fused20m_image_floats(n_hidden) * 4 + (size_t)(4 * FROWS + 4) * 65 * 16;
+}
+
+// Called by every kernel that writes a weight: mirrors flat parameter i into the LDS image.
+__device__ __forceinline__ void pack_store_m(const NetDesc& nd, float* __restrict__ img, int i, float v) {
+  if (!img) return;
+  const int lo = nd.off_w[1], hi = nd.off_w[nd.n_hidden];
+  if (i < lo || i >= hi) return;
+  constexpr int PER = FW * FW + FW;
+  const int d1 = (i - lo) / PER, rem = (i - lo) - d1 * PER;
+  float* __restrict__ base = img + d1 * WIMG;
+  if (rem < FW * FW) {
+    const int k = rem / FW, j = rem - k * FW;
+    base[j * FW + k] = v;
+    base[FW * FW + rem] = v;
+  } else {
+    base[2 * FW * FW + rem - FW * FW] = v;
+  }
+}
+
+typedef float acc4 __attribute__((ext_vector_type(4)));
+
+// acc_own[c][i] += sum_k P[(f_own+i)][k] in_c[k]   (c = 0..3)  -- 80 MFMAs
+// acc_g4[i]     += sum_k P[(16+i)][k]    in_wave[k]            -- 20 MFMAs (channel = wave index)
+// P = 20x20 row-major pattern matrix in LDS (W^T forward, W reverse); in = 20 float4 tiles rows.
+template <typename SIDE>
+__device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, const float* __restrict__ P,
+                                          const int wave, const int lane, const v4f (&in)[FW], SIDE side) {
+  const v4f* __restrict__ po = reinterpret_cast<const v4f*>(P + (4 * wave + (lane & 3)) * FW);
+  const v4f* __restrict__ pg = reinterpret_cast<const v4f*>(P + (16 + (lane & 3)) * FW);
+  v4f ao[5], ag[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) { ao[m] = po[m]; ag[m] = pg[m]; }
+#pragma unroll
+  for (int k = 0; k < FW; ++k) {
+    const float a = ao[k >> 2][k & 3];
+    acc_own[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].x, acc_own[0], 0, 0, 0);
+    acc_own[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].y, acc_own[1], 0, 0, 0);
+    side(2 * k);
+    acc_own[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].z, acc_own[2], 0, 0, 0);
+    acc_own[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].w, acc_own[3], 0, 0, 0);
+    side(2 * k + 1);
+  }
+  // group 4, one channel per wave (uniform branch; only the selected 20 MFMAs execute); two
+  // accumulators so that consecutive MFMAs do not depend on each other
+  acc4 g4b = {0, 0, 0, 0};
+#define G4_CHAIN(COMP)                                                                             \
+  _Pragma("unroll") for (int k = 0; k < FW; k += 2) {                                              \
+    acc_g4 = __builtin_amdgcn_mfma_f32_4x4x1f32(ag[k >> 2][k & 3], in[k].COMP, acc_g4, 0, 0, 0);   \
+    g4b = __builtin_amdgcn_mfma_f32_4x4x1f32(ag[(k + 1) >> 2][(k + 1) & 3], in[k + 1].COMP, g4b, 0, 0, 0); \
+  }
+  if (wave == 0) { G4_CHAIN(x) } else if (wave == 1) { G4_CHAIN(y) } else if (wave == 2) { G4_CHAIN(z) } else { G4_CHAIN(w) }
+#undef G4_CHAIN
+  acc_g4 += g4b;
+}
+
+template <int PDE, int H>
+__global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
+                                                  const float* __restrict__ th,
+                                                  const float* __restrict__ img,
+                                                  const float* __restrict__ xs,
+                                                  const float* __restrict__ ts,
+                                                  const float* __restrict__ tgt, float lbx, float lbt,
+                                                  float sx, float st, float nu,
+                                                  float* __restrict__ part, int R, int n_tiles,
+                                                  long long* __restrict__ stamps) {
+  constexpr int RS4 = 65;
+  constexpr int BUFV = FROWS * RS4;                 // v4f elements per exchange buffer
+  constexpr int NW = (H - 1) * WIMG;                // floats of weight image
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  v4f* const xb = reinterpret_cast<v4f*>(wl + NW);
+  v4f* const Q = xb + 4 * BUFV;                     // group-4 meeting point: [4][RS4] float4
+  float* const Qf = reinterpret_cast<float*>(Q);
+
+  STAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* __restrict__ row = part + (size_t)blockIdx.x * R;
+  // this wave's features: local jj = 0..3 -> 4*wave + jj, jj = 4 -> 16 + wave
+  auto feat = [&](int jj) { return jj < 4 ? 4 * wave + jj : 16 + wave; };
+
+  // first tile's coordinates: issued ahead of the weight staging
+  int tile = blockIdx.x;
+  float x = 0.0f, t = 0.0f;
+  if (tile < n_tiles) { x = xs[tile * 64 + lane]; t = ts[tile * 64 + lane]; }
+
+  // ---- stage the weight image (16-byte copies) and the two "ones" rows
+  for (int i = tid; i < NW / 4; i += 256)
+    reinterpret_cast<v4f*>(wl)[i] = reinterpret_cast<const v4f*>(img)[i];
+  if (wave == 0) {
+    xb[0 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
+    xb[2 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
+  }
+  // first / last dense layer parameters of this wave (wave-uniform)
+  float w0x[FF], w0t[FF], b0[FF], wLo[FF], wL[FW];
+#pragma unroll
+  for (int jj = 0; jj < FF; ++jj) {
+    w0x[jj] = th[nd.off_w[0] + feat(jj)];
+    w0t[jj] = th[nd.off_w[0] + FW + feat(jj)];
+    b0[jj] = th[nd.off_b[0] + feat(jj)];
+    wLo[jj] = th[nd.off_w[H] + feat(jj)];
+  }
+#pragma unroll
+  for (int k = 0; k < FW; ++k) wL[k] = th[nd.off_w[H] + k];
+  const float bL = th[nd.off_b[H]];
+  float c1 = 1.0f, c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = __expf(th[nd.n_net + 1]); }
+  const float inv_nf = (float)sd.inv_nf, inv_nu = (float)sd.inv_nu;
+
+  // accumulators that live across tiles
+  acc4 dw[H][2];          // dw[d][0..1], d = 1..H-1: this wave's 16x16 tile of dW_d, split over two
+                          // accumulators (channels h,q / p,r) so consecutive MFMAs never depend
+#pragma unroll
+  for (int d = 0; d < H; ++d) dw[d][0] = dw[d][1] = acc4{0, 0, 0, 0};
+  float g0x[FF], g0t[FF], g0b[FF], gH[FF];
+#pragma unroll
+  for (int jj = 0; jj < FF; ++jj) g0x[jj] = g0t[jj] = g0b[jj] = gH[jj] = 0.0f;
+  float gHb = 0.0f, l_res = 0.0f, l_dat = 0.0f, dl0 = 0.0f, dl1 = 0.0f;
+
+  const int ti = wave >> 1, tj = wave & 1;                    // this wave's 16x16 tile of dW
+  const int fa = min(16 * ti + (lane & 15), FW);              // A row: input feature (20 = ones)
+  const int fb = min(16 * tj + (lane & 15), FW - 1);          // B column: output feature
+  const int kq = (lane >> 4) * 16;                            // this lane group's 16 points
+  const int qw = 4 * lane + wave;                             // float index of (point, channel = wave) in a Q row
+  __syncthreads();                                            // weights staged
+  STAMP(1);
+
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int pt = tile * 64 + lane;
+    const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t - lbt, -1.0f);
+    {  // next tile's coordinates: in flight during this tile
+      const int nt = tile + gridDim.x;
+      if (nt < n_tiles) { x = xs[nt * 64 + lane]; t = ts[nt * 64 + lane]; }
+    }
+    v4f stash[H][FF];                            // AGPR-resident (agpr_put4 / agpr_get4)
+
+    // ------------------------------------------------------------------ forward
+#pragma unroll
+    for (int jj = 0; jj < FF; ++jj) {            // dense 0: p0 = (sx, 0), q0 = (0, st), r0 = 0
+      const float z = fmaf(hx, w0x[jj], fmaf(ht, w0t[jj], b0[jj]));
+      const v4f s{tanh_r5(z), sx * w0x[jj], st * w0t[jj], 0.0f};
+      stash[0][jj] = agpr_put4(s);
+      xb[feat(jj) * RS4 + lane] = channels4(s);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int d = 1; d < H; ++d) {
+      const v4f* __restrict__ Xin = xb + ((d - 1) & 1) * BUFV;
+      v4f* __restrict__ Xout = xb + (d & 1) * BUFV;
+      const float* __restrict__ wimg = wl + (d - 1) * WIMG;
+      v4f xin[FW];
+#pragma unroll
+      for (int k = 0; k < FW; ++k) xin[k] = Xin[k * RS4 + lane];
+      acc4 acc_own[4], acc_g4;
+      acc_own[0] = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 4 * wave);     // bias b_d[4w..4w+3]
+      acc_own[1] = acc_own[2] = acc_own[3] = acc4{0, 0, 0, 0};
+      acc_g4 = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 16);
+      if (wave != 0) acc_g4 = acc4{0, 0, 0, 0};                                      // bias rides on channel h
+      if (d == 4) STAMP(24);
+      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, xin, [](int) {});
+      if (d == 4) STAMP(25);
+      // group 4: publish this wave's channel of features 16..19, then finish the own group
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = acc_g4[i];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const v4f s{tanh_r5(acc_own[0][jj]), acc_own[1][jj], acc_own[2][jj], acc_own[3][jj]};
+        stash[d][jj] = agpr_put4(s);
+        Xout[(4 * wave + jj) * RS4 + lane] = channels4(s);
+      }
+      if (d == 4) STAMP(26);
+      lds_barrier();
+      if (d == 4) STAMP(27);
+      {
+        const v4f z4 = Q[wave * RS4 + lane];      // feature 16+wave: (h, p, q, r) pre-activations
+        const v4f s{tanh_r5(z4.x), z4.y, z4.z, z4.w};
+        stash[d][4] = agpr_put4(s);
+        Xout[(16 + wave) * RS4 + lane] = channels4(s);
+      }
+      lds_barrier();
+      STAMP(1 + d);
+    }
+    // linear output layer (every wave computes it) -> o = (u, u_x, u_t, u_xx)
+    v4f o{bL, 0, 0, 0};
+    {
+      const v4f* __restrict__ Xin = xb + ((H - 1) & 1) * BUFV;
+      v4f xin[FW];
+#pragma unroll
+      for (int k = 0; k < FW; ++k) xin[k] = Xin[k * RS4 + lane];
+#pragma unroll
+      for (int k = 0; k < FW; ++k) {
+        o.x = fmaf(xin[k].x, wL[k], o.x); o.y = fmaf(xin[k].y, wL[k], o.y);
+        o.z = fmaf(xin[k].z, wL[k], o.z); o.w = fmaf(xin[k].w, wL[k], o.w);
+      }
+    }
+
+    // ------------------------------------------------------------------ seeds + loss parts
+    v4f sb{0, 0, 0, 0};
+    {
+      const int cls = point_class(sd, pt);
+      const bool res = (PDE == 0) ? (cls == CLS_COL) : (cls == CLS_DATA);
+      if (res) {
+        const float wgt = (PDE == 0) ? inv_nf : inv_nu;
+        const float f = o.z + c1 * o.x * o.y - c2 * o.w;
+        const float fbar = 2.0f * f * wgt;
+        l_res += f * f * wgt;
+        sb = v4f{fbar * c1 * o.y, fbar * c1 * o.x, fbar, -c2 * fbar};
+        if (PDE == 1) { dl0 += fbar * o.x * o.y; dl1 -= fbar * c2 * o.w; }
+      }
+      if (cls == CLS_DATA) {
+        const float dd = o.x - tgt[pt];
+        l_dat += dd * dd * inv_nu;
+        sb.x += 2.0f * dd * inv_nu;
+      }
+    }
+
+    // ------------------------------------------------------------------ reverse sweep
+    v4f ob[FF];                              // adjoint of the outputs of the layer below, own features
+    {  // dense H (linear): z_bar = sb
+      gHb += sb.x;
+#pragma unroll
+      for (int kk = 0; kk < FF; ++kk) {
+        const v4f in = channels4(agpr_get4(stash[H - 1][kk]));
+        gH[kk] += fmaf(in.w, sb.w, fmaf(in.z, sb.z, fmaf(in.y, sb.y, in.x * sb.x)));
+        ob[kk] = sb * wLo[kk];
+      }
+    }
+    lds_barrier();          // every wave is done reading the forward tile before it is overwritten
+    STAMP(H + 1);
+#pragma unroll
+    for (int d = H - 1; d >= 1; --d) {
+      const int pair = (H - 1 - d) & 1;
+      v4f* __restrict__ IN = xb + (2 * pair) * BUFV;
+      v4f* __restrict__ ZB = xb + (2 * pair + 1) * BUFV;
+      // phase A: publish own z_bar (layer d) and own layer-(d-1) output channels
+#pragma unroll
+      for (int kk = 0; kk < FF; ++kk) {
+        ZB[feat(kk) * RS4 + lane] = preact_adjoint4(agpr_get4(stash[d][kk]), ob[kk]);
+        IN[feat(kk) * RS4 + lane] = channels4(agpr_get4(stash[d - 1][kk]));
+      }
+      if (d == 4) STAMP(28);
+      lds_barrier();
+      if (d == 4) STAMP(29);
+      // phase B: adjoint of own layer-(d-1) outputs  in_bar[k] = sum_j z_bar_j W_d[k][j]  (4x4x1 MFMAs)
+      //          and dW_d tile += IN^T . ZB over the 256 (point,channel) rows (16x16x4 MFMAs),
+      //          one of the latter after every pair of the former
+      const float* __restrict__ wimg = wl + (d - 1) * WIMG + FW * FW;
+      v4f zin[FW];
+#pragma unroll
+      for (int j = 0; j < FW; ++j) zin[j] = ZB[j * RS4 + lane];
+      v4f a4[2], b4[2];                        // 16x16x4 operand ring: group j in slot j & 1
+      a4[0] = IN[fa * RS4 + kq + 0]; b4[0] = ZB[fb * RS4 + kq + 0];
+      a4[1] = IN[fa * RS4 + kq + 1]; b4[1] = ZB[fb * RS4 + kq + 1];
+      acc4 acc_own[4], acc_g4 = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc_own[c] = acc4{0, 0, 0, 0};
+      acc4 acc0 = dw[d][0], acc1 = dw[d][1];
+      auto dw_mfma = [&](int m) {              // m = 0..63: group j = m/4, channel m%4
+        const int j = m >> 2, c = m & 3;
+        const v4f a = a4[j & 1], b = b4[j & 1];
+        if (c == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
+        if (c == 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
+        if (c == 2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
+        if (c == 3) {
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
+          if (j + 2 < 16) {                    // refill this ring slot two groups ahead
+            a4[j & 1] = IN[fa * RS4 + kq + j + 2];
+            b4[j & 1] = ZB[fb * RS4 + kq + j + 2];
+          }
+        }
+      };
+      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, zin, [&](int slot) { dw_mfma(slot); });   // slots 0..39
+#pragma unroll
+      for (int m = 2 * FW; m < 64; ++m) dw_mfma(m);
+      dw[d][0] = acc0; dw[d][1] = acc1;
+      if (d == 4) STAMP(30);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = acc_g4[i];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) ob[kk] = v4f{acc_own[0][kk], acc_own[1][kk], acc_own[2][kk], acc_own[3][kk]};
+      lds_barrier();
+      ob[4] = Q[wave * RS4 + lane];
+      STAMP(2 * H + 1 - d);
+    }
+    {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
+#pragma unroll
+      for (int kk = 0; kk < FF; ++kk) {
+        const v4f zb = preact_adjoint4(agpr_get4(stash[0][kk]), ob[kk]);
+        g0x[kk] += fmaf(hx, zb.x, sx * zb.y);
+        g0t[kk] += fmaf(ht, zb.x, st * zb.z);
+        g0b[kk] += zb.x;
+      }
+    }
+    lds_barrier();          // the next tile's first layer overwrites an exchange buffer
+  }
+  STAMP(2 * H + 1);
+
+  // -------------------------------------------------------------------- one gradient row per workgroup
+  {
+#pragma unroll
+    for (int kk = 0; kk < FF; ++kk) {
+      const float a = wave_sum(g0x[kk]), b = wave_sum(g0t[kk]), c = wave_sum(g0b[kk]), e = wave_sum(gH[kk]);
+      if (lane == 0) {
+        const int f = feat(kk);
+        row[nd.off_w[0] + f] = a;
+        row[nd.off_w[0] + FW + f] = b;
+        row[nd.off_b[0] + f] = c;
+        row[nd.off_w[H] + f] = e;
+      }
+    }
+    if (wave == 0) {
+      const float a = wave_sum(l_res), b = wave_sum(l_dat), g = wave_sum(gHb);
+      if (lane == 0) {
+        row[nd.n_theta + 0] = a; row[nd.n_theta + 1] = b; row[nd.n_theta + 2] = 0.0f;
+        row[nd.off_b[H]] = g;
+      }
+      if (PDE == 1) {
+        const float g1 = wave_sum(dl0), g2 = wave_sum(dl1);
+        if (lane == 0) { row[nd.n_net] = g1; row[nd.n_net + 1] = g2; }
+      }
+    }
+    STAMP(31);
+    // dW / db tiles: lane (l & 15) holds output feature jg, VGPR r holds input feature ig (20 = bias
+    // row); b_d sits right behind W_d in the flat layout, so one offset serves both
+    const int jg = 16 * tj + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ig = 16 * ti + (lane >> 4) * 4 + r;
+      if (jg < FW && ig <= FW) {
+        float* __restrict__ dst = row + nd.off_w[1] + ig * FW + jg;
+#pragma unroll
+        for (int d = 1; d < H; ++d) dst[(d - 1) * (FW * FW + FW)] = dw[d][0][r] + dw[d][1][r];
+      }
+    }
+  }
+  STAMP(2 * H + 2);
+}
+
+// returns a hipError_t (0 = ok)
+template <int PDE, int H>
+inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th, const float* img,
+                           const float* xs, const float* ts, const float* tgt, float lbx, float lbt,
+                           float sx, float st, float nu, float* part, int R, int n_wg,
+                           hipStream_t stream, long long* stamps = nullptr) {
+  const size_t lds = fused20m_lds_bytes(H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused20m<PDE, H>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
+                     ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pinn

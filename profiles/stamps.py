@@ -54,6 +54,17 @@ def main():
     for i, nme in enumerate(names):
         print("%-34s %10.0f %10.0f %10.0f" % (nme, np.median(per[:, i]), per[:, i].min(), per[:, i].max()))
     print("%-34s %10.0f" % ("sum of medians", np.median(per, axis=0).sum()))
+    if path == 2:
+        full = eng.debug_stamps().astype(np.float64).reshape(-1, 4, 32)
+        H_ = H
+        def seg(a, b):
+            return np.median((full[:, :, b] - full[:, :, a]).max(axis=1))
+        print("# layer 4 detail (slowest wave per workgroup, median): ")
+        print("#  fwd: reads issued..gemv start %.0f | gemv %.0f | Q write + own nonlinear %.0f | barrier wait %.0f | g4 tail+barrier %.0f" % (
+            seg(1 + 3, 24), seg(24, 25), seg(25, 26), seg(26, 27), seg(27, 1 + 4)))
+        print("#  epilogue: wave sums + first/last layer rows %.0f | dW scatter %.0f" % (seg(2 * H_ + 1, 31), seg(31, 2 * H_ + 2)))
+        print("#  bwd: phase A %.0f | barrier wait %.0f | phase B (gemv + dW) %.0f | Q exchange %.0f" % (
+            seg(2 * H_ + 1 - 5, 28), seg(28, 29), seg(29, 30), seg(30, 2 * H_ + 1 - 4)))
     eng.close()
 
 
