@@ -61,9 +61,11 @@ typedef float acc4 __attribute__((ext_vector_type(4)));
 // acc_own[c][i] += sum_k P[(f_own+i)][k] in_c[k]   (c = 0..3)  -- 80 MFMAs
 // acc_g4[i]     += sum_k P[(16+i)][k]    in_wave[k]            -- 20 MFMAs (channel = wave index)
 // P = 20x20 row-major pattern matrix in LDS (W^T forward, W reverse); in = 20 float4 tiles rows.
-template <typename SIDE>
+// g4_ready(acc_g4) is called as soon as the group-4 unit is complete (the caller publishes it).
+template <typename G4, typename SIDE>
 __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, const float* __restrict__ P,
-                                          const int wave, const int lane, const v4f (&in)[FW], SIDE side) {
+                                          const int wave, const int lane, const v4f (&in)[FW],
+                                          G4 g4_ready, SIDE side) {
   const v4f* __restrict__ po = reinterpret_cast<const v4f*>(P + (4 * wave + (lane & 3)) * FW);
   const v4f* __restrict__ pg = reinterpret_cast<const v4f*>(P + (16 + (lane & 3)) * FW);
   v4f ao[5], ag[5];
@@ -79,8 +81,9 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
     acc_own[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].w, acc_own[3], 0, 0, 0);
     side(2 * k + 1);
   }
-  // group 4, one channel per wave (uniform branch; only the selected 20 MFMAs execute); two
-  // accumulators so that consecutive MFMAs do not depend on each other
+  // group 4, one channel per wave: uniform branch, only the selected 20 MFMAs execute; two
+  // accumulators so that consecutive MFMAs do not depend on each other.  (Running this unit
+  // first, to cover its LDS exchange with the own-group MFMAs, measured 5 % slower per layer.)
   acc4 g4b = {0, 0, 0, 0};
 #define G4_CHAIN(COMP)                                                                             \
   _Pragma("unroll") for (int k = 0; k < FW; k += 2) {                                              \
@@ -90,6 +93,7 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
   if (wave == 0) { G4_CHAIN(x) } else if (wave == 1) { G4_CHAIN(y) } else if (wave == 2) { G4_CHAIN(z) } else { G4_CHAIN(w) }
 #undef G4_CHAIN
   acc_g4 += g4b;
+  g4_ready(acc_g4);
 }
 
 template <int PDE, int H>
@@ -197,11 +201,14 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       acc_g4 = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 16);
       if (wave != 0) acc_g4 = acc4{0, 0, 0, 0};                                      // bias rides on channel h
       if (d == 4) STAMP(24);
-      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, xin, [](int) {});
-      if (d == 4) STAMP(25);
-      // group 4: publish this wave's channel of features 16..19, then finish the own group
+      // group 4: this wave's channel of features 16..19 is published as soon as it is complete
+      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, xin,
+                [&](const acc4& g) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = acc_g4[i];
+                  for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = g[i];
+                },
+                [](int) {});
+      if (d == 4) STAMP(25);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const v4f s{tanh_r5(acc_own[0][jj]), acc_own[1][jj], acc_own[2][jj], acc_own[3][jj]};
@@ -309,13 +316,16 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
           }
         }
       };
-      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, zin, [&](int slot) { dw_mfma(slot); });   // slots 0..39
+      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, zin,
+                [&](const acc4& g) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = g[i];
+                },
+                [&](int slot) { dw_mfma(slot); });   // slots 0..39
 #pragma unroll
       for (int m = 2 * FW; m < 64; ++m) dw_mfma(m);
       dw[d][0] = acc0; dw[d][1] = acc1;
       if (d == 4) STAMP(30);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = acc_g4[i];
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) ob[kk] = v4f{acc_own[0][kk], acc_own[1][kk], acc_own[2][kk], acc_own[3][kk]};
       lds_barrier();
@@ -337,27 +347,42 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
 
   // -------------------------------------------------------------------- one gradient row per workgroup
   {
+    // 25 per-lane partials -> lane totals through this wave's slice of the (now free) exchange
+    // area: 25 row writes, then lane (v, half) adds up 32 entries of row v with 8 ds_read_b128 and
+    // the two halves meet through one bpermute.  (A DPP butterfly per value costs ~3x the issue slots.)
+    constexpr int NV = 25, RSF = 68;                 // rows; padded row stride in floats (16-B aligned)
+    float* __restrict__ red = reinterpret_cast<float*>(xb) + wave * (NV * RSF);
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) {
-      const float a = wave_sum(g0x[kk]), b = wave_sum(g0t[kk]), c = wave_sum(g0b[kk]), e = wave_sum(gH[kk]);
-      if (lane == 0) {
-        const int f = feat(kk);
-        row[nd.off_w[0] + f] = a;
-        row[nd.off_w[0] + FW + f] = b;
-        row[nd.off_b[0] + f] = c;
-        row[nd.off_w[H] + f] = e;
-      }
+      red[(0 + kk) * RSF + lane] = g0x[kk];
+      red[(5 + kk) * RSF + lane] = g0t[kk];
+      red[(10 + kk) * RSF + lane] = g0b[kk];
+      red[(15 + kk) * RSF + lane] = gH[kk];
     }
-    if (wave == 0) {
-      const float a = wave_sum(l_res), b = wave_sum(l_dat), g = wave_sum(gHb);
-      if (lane == 0) {
-        row[nd.n_theta + 0] = a; row[nd.n_theta + 1] = b; row[nd.n_theta + 2] = 0.0f;
-        row[nd.off_b[H]] = g;
-      }
-      if (PDE == 1) {
-        const float g1 = wave_sum(dl0), g2 = wave_sum(dl1);
-        if (lane == 0) { row[nd.n_net] = g1; row[nd.n_net + 1] = g2; }
-      }
+    red[20 * RSF + lane] = l_res; red[21 * RSF + lane] = l_dat; red[22 * RSF + lane] = gHb;
+    red[23 * RSF + lane] = dl0;   red[24 * RSF + lane] = dl1;
+    const int v = lane & 31, half = lane >> 5;
+    float tot = 0.0f;
+    if (v < NV) {
+      const v4f* __restrict__ src = reinterpret_cast<const v4f*>(red + v * RSF + 32 * half);
+      v4f q[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) q[m] = src[m];
+      v4f s4 = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+      tot = (s4.x + s4.y) + (s4.z + s4.w);
+    }
+    tot += __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __float_as_int(tot)));
+    if (lane < 20) {
+      const int grp = lane / 5, kk = lane - grp * 5;
+      const int f = kk < 4 ? 4 * wave + kk : 16 + wave;
+      const int base = grp == 0 ? nd.off_w[0] : grp == 1 ? nd.off_w[0] + FW : grp == 2 ? nd.off_b[0] : nd.off_w[H];
+      row[base + f] = tot;
+    } else if (wave == 0 && lane < NV) {
+      if (lane == 20) { row[nd.n_theta + 0] = tot; row[nd.n_theta + 2] = 0.0f; }
+      if (lane == 21) row[nd.n_theta + 1] = tot;
+      if (lane == 22) row[nd.off_b[H]] = tot;
+      if (PDE == 1 && lane == 23) row[nd.n_net] = tot;
+      if (PDE == 1 && lane == 24) row[nd.n_net + 1] = tot;
     }
     STAMP(31);
     // dW / db tiles: lane (l & 15) holds output feature jg, VGPR r holds input feature ig (20 = bias
