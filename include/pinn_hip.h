@@ -117,7 +117,9 @@ int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank);
 /* Measurement: bracket launches of the dominant kernel (the loss+grad kernels) with hipEvents
  * on the engine's stream.  An event record costs ~5 us on the GPU timeline, so only one
  * evaluation out of `every` is sampled (at most max_evals samples).  pinn_timing_read drains
- * them: avg_ms[0] forward sweep, avg_ms[1] forward+reverse sweeps, avg_ms[2] whole evaluation;
+ * them into avg_ms[4]: [0] forward sweep, [1] forward+reverse sweeps (the loss+grad kernel),
+ * [2] whole evaluation, [3] what an EMPTY event bracket reads on this stream (calibrated at
+ * enable time; subtract it from [0..2] to compare with rocprofv3 kernel durations);
  * n = evaluations sampled. */
 int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);

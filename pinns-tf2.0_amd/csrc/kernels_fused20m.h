@@ -1,7 +1,15 @@
 // kernels_fused20m.h -- float32 loss+gradient kernel for width-20 tanh MLPs, every contraction on
-// the matrix instructions (k_fused20m).  Successor of k_fused20r (kernels_fused20r.h): same
-// workgroup (4 waves, lane = point, 64-point tiles, persistent), same register (AGPR) stash, same
-// 16x16x4 weight-gradient tiles; what changes is the layer GEMVs.
+// the matrix instructions (k_fused20m).  Same workgroup mapping as k_fused20 (kernels_fused20.h:
+// 4 waves, lane = point, 64-point tiles, LDS exchange tiles, 16x16x4 weight-gradient tiles), with
+//   * persistent workgroups (grid = min(tiles, CUs)); weight-gradient accumulators and the first/
+//     last-layer partial sums live in registers across tiles, one gradient row per workgroup;
+//   * the Taylor-channel stash (a, z_x, z_t, z_xx) of the wave's 5 features x H layers parked
+//     explicitly in AGPRs (160 of the 512-register budget of a one-wave-per-SIMD kernel): no HBM
+//     stash, the only global traffic is 8 B/point, the 23 KB weight image and the gradient row;
+//   * both layer loops fully unrolled (H is a template parameter);
+//   * the layer GEMVs on v_mfma_f32_4x4x1_16B_f32 (below).  Its predecessor with packed-FMA GEMVs
+//     (weights lane-distributed, v_readlane -> SGPR operand) measured 72k cycles per tile against
+//     64k here (git history: kernels_fused20r.h).
 //
 // Measured on gfx950 (profiles/r01_ubench_*.txt): a lone wave per SIMD issues one instruction per
 // ~5.3 cycles, and v_mfma_f32_* shares the FP32 datapath with the vector ALU (an MFMA and packed
@@ -28,9 +36,61 @@
 // Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
 // the outer tape of utils/neuralnetwork.py:55-59.
 #pragma once
-#include "kernels_fused20r.h"
+#include "kernels_fused20.h"
 
 namespace pinn {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// The per-layer stash lives in the accumulation half of the unified register file: parking it
+// there explicitly (instead of letting the allocator spill to AGPRs) keeps it out of the VGPR
+// pressure the scheduler reasons about, so LDS reads can be hoisted well ahead of their use.
+__device__ __forceinline__ float agpr_put(const float x) {
+  float a;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
+  return a;
+}
+__device__ __forceinline__ float agpr_get(const float a) {
+  float x;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+  return x;
+}
+__device__ __forceinline__ v4f agpr_put4(const v4f s) {
+  return v4f{agpr_put(s.x), agpr_put(s.y), agpr_put(s.z), agpr_put(s.w)};
+}
+__device__ __forceinline__ v4f agpr_get4(const v4f a) {
+  return v4f{agpr_get(a.x), agpr_get(a.y), agpr_get(a.z), agpr_get(a.w)};
+}
+
+// tanh(x) = 1 - 2 / (1 + e^{2x}); absolute error ~1 ulp of 1.0 (cf. tanh_bf)
+__device__ __forceinline__ float tanh_r5(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+
+// layer-output channels (h, p, q, r) from a stash entry s = (a, zp, zq, zr)
+__device__ __forceinline__ v4f channels4(const v4f s) {
+  const float a = s.x, d1 = fmaf(-a, a, 1.0f);
+  const float t = (-2.0f * a) * s.y;
+  return v4f{a, d1 * s.y, d1 * s.z, d1 * fmaf(t, s.y, s.w)};
+}
+
+// adjoint of the pre-activation channels (A.3)
+__device__ __forceinline__ v4f preact_adjoint4(const v4f s, const v4f ob) {
+  const float a = s.x, a2 = a * a, d1 = 1.0f - a2;
+  const float d2 = (-2.0f * a) * d1;
+  const float d3 = (-2.0f * d1) * fmaf(-3.0f, a2, 1.0f);
+  const float zpw = s.y * ob.w;
+  const float dot = fmaf(s.w, ob.w, fmaf(s.z, ob.z, s.y * ob.y));
+  v4f zb;
+  zb.x = fmaf(d3 * s.y, zpw, fmaf(d2, dot, d1 * ob.x));
+  zb.y = fmaf(d2 + d2, zpw, d1 * ob.y);
+  zb.z = d1 * ob.z;
+  zb.w = d1 * ob.w;
+  return zb;
+}
+
 
 constexpr int WIMG = 820;
 

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_optim.h", "wave.h"]
+SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
 PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2}
@@ -315,10 +315,11 @@ class Engine(object):
         self._check(self._lib.pinn_timing_enable(self._h, int(max_evals), int(every)))
 
     def timing_read(self):
-        ms = np.zeros(3, dtype=np.float64)
+        ms = np.zeros(4, dtype=np.float64)
         n = ctypes.c_int(0)
         self._check(self._lib.pinn_timing_read(self._h, _dp(ms), ctypes.byref(n)))
-        return {"fwd_ms": ms[0], "sweeps_ms": ms[1], "eval_ms": ms[2], "n": n.value}
+        return {"fwd_ms": ms[0], "sweeps_ms": ms[1], "eval_ms": ms[2], "empty_bracket_ms": ms[3],
+                "n": n.value}
 
     def sync(self):
         self._check(self._lib.pinn_sync(self._h))
