@@ -15,6 +15,7 @@
 #include "../../include/pinn_hip.h"
 #include "kernels_fused20.h"
 #include "kernels_fused20m.h"
+#include "kernels_wide.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
 
@@ -145,6 +146,11 @@ static bool fused_regs_ok(const pinn_ctx* c) {
          c->nd.n_hidden == 8 && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
 }
 
+// the wide MFMA sweeps: float32, hidden width 100, two outputs (the Schrodinger net)
+static bool wide_ok(const pinn_ctx* c) {
+  return c->dtype == PINN_F32 && c->nd.width == 100 && c->nd.n_out == 2 && c->nd.n_hidden >= 2;
+}
+
 template <typename T>
 static int dev_alloc(T** p, size_t bytes) {
   if (*p) (void)hipFree(*p);
@@ -268,6 +274,25 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     for (int base = 0, ci = 0; base < sd.n_pad; base += c->chunk, ++ci) {
       const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
       const dim3 grid(pts / 64), block(64);
+      bool fwd_done = false;
+      if constexpr (sizeof(real) == 4) {
+        if (c->path == 3) {
+          static bool attr = false;
+          if (!attr) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_wide_fwd<100, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)wide_lds_bytes<100>()));
+            attr = true;
+          }
+          const int n_groups = pts / 16;
+          const int wg = n_groups < c->n_cu ? n_groups : c->n_cu;
+          hipLaunchKernelGGL((k_wide_fwd<100, 2>), dim3(wg), dim3(256), wide_lds_bytes<100>(), c->stream, c->nd,
+                             (const float*)c->theta_r, c->img, (const float*)c->xs, (const float*)c->ts, base,
+                             sd.n_pad, c->chunk, n_groups, (float)lbx, (float)lbt, (float)sx, (float)st,
+                             (vec4<float>*)c->S, (vec4<float>*)c->O);
+          fwd_done = true;
+        }
+      }
+      if (!fwd_done)
       hipLaunchKernelGGL((k_forward<real, JT>), grid, block, 0, c->stream, c->nd,
                          (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, base,
                          sd.n_pad, c->chunk, lbx, lbt, sx, st, (vec4<real>*)c->S,
@@ -403,8 +428,17 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
     HIPCHK(hipMemsetAsync(c->img, 0, nimg * 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
   }
-  // width-20 Burgers nets take a fused path by default (2: f32 register-stash, 1: HBM-stash)
-  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : 0;
+  if (fused_regs_ok(c)) nd.img_kind = 1;
+  if (wide_ok(c)) {
+    const size_t nimg = wide_image_floats<100>(nd.n_hidden);
+    if (dev_alloc(&c->img, nimg * 4)) { delete c; return PINN_EHIP; }
+    HIPCHK(hipMemsetAsync(c->img, 0, nimg * 4, c->stream));   // the zero padding is never rewritten
+    HIPCHK(hipStreamSynchronize(c->stream));
+    nd.img_kind = 2;
+  }
+  // default kernel family: 2 width-20 f32 (MFMA GEMVs, register stash), 1 width-20 HBM-stash,
+  // 3 wide MFMA sweeps (width 100, 2 outputs), 0 generic
+  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : 0;
   *out = c;
   return 0;
 }
@@ -831,7 +865,8 @@ int pinn_sync(pinn_ctx* c) {
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
-  REQUIRE(c && path >= 0 && path <= 2, "path must be 0 (generic), 1 (fused width-20) or 2 (fused width-20, register stash)");
+  REQUIRE(c && path >= 0 && path <= 3, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash) or 3 (wide MFMA sweeps)");
+  if (path == 3) REQUIRE(wide_ok(c), "the wide path needs float32, hidden width 100 and two outputs");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");
   if (path == 2)

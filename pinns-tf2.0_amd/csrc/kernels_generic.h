@@ -23,6 +23,7 @@ struct NetDesc {
   int off_b[MAX_DENSE];
   int n_net;                 // number of network scalars (without lambdas)
   int n_theta;               // n_net (+2 for identification)
+  int img_kind;              // packed weight image kept by the optimiser kernels: 0 none, 1 k_fused20m, 2 wide
 };
 
 // Training-set geometry for one evaluation.  Points are stored in class order

@@ -3,7 +3,7 @@
 // float64 end to end, utils/neuralnetwork.py:24-26); the compute kernels read a `real`
 // mirror of the weights that these kernels keep in sync.
 #pragma once
-#include "kernels_fused20m.h"
+#include "kernels_wide.h"
 
 namespace pinn {
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_adam(const real* __restr
     const double t = theta[c] - alpha * mi / (sqrt(vi) + eps);
     theta[c] = t;
     theta_r[c] = (real)t;
-    pack_store_m(nd, img, c, (float)t);
+    pack_store_any(nd, img, c, (float)t);
   } else if (loss3 && c < n + 3) {
     loss3[c - n] = g;
   }
@@ -107,14 +107,14 @@ __global__ void k_adam(int n, const double* __restrict__ gl, double* __restrict_
   const double t = theta[i] - alpha * mi / (sqrt(vi) + eps);
   theta[i] = t;
   theta_r[i] = (real)t;
-  pack_store_m(nd, img, i, (float)t);
+  pack_store_any(nd, img, i, (float)t);
 }
 
 template <typename real>
 __global__ void k_cast_weights(int n, const double* __restrict__ theta, real* __restrict__ theta_r,
                                NetDesc nd, float* __restrict__ img) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { theta_r[i] = (real)theta[i]; pack_store_m(nd, img, i, (float)theta[i]); }
+  if (i < n) { theta_r[i] = (real)theta[i]; pack_store_any(nd, img, i, (float)theta[i]); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
   for (int i = tid; i < n; i += LB_THREADS) {
     const double xi = x[i] + t * d[i];                 // :174
     x[i] = xi;
-    if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_m(nd, img, i, (float)xi); }
+    if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
   }
   if (tid == 0) {
     st->n_iter = n_iter; st->hist_len = hist_len; st->hist_head = head; st->Hdiag = Hdiag;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64 * LBA_SLICES) void k_lbc_apply(
   g_old[i] = gi;
   const double xi = xi0 + t * di;
   x[i] = xi;
-  if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_m(nd, img, i, (float)xi); }
+  if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
 }
 
 }  // namespace pinn

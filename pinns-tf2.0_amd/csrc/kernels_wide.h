@@ -1,0 +1,225 @@
+// kernels_wide.h -- float32 forward / reverse sweeps for WIDE tanh MLPs (hidden width W a multiple
+// of 4, 64 < W <= 128: the Schrodinger net [2,100,100,100,100,2] of
+// 1dcomplex-schrodinger/inf_cont_schrodinger.py:23-41), every contraction on v_mfma_f32_16x16x4_f32.
+//
+// At width 100 a layer is a real GEMM ([points x 4 channels] x [100 x 100]) and the 64-point tile of
+// the width-20 kernels no longer fits LDS (100 features x 64 points x 4 channels x 4 B = 102 KB per
+// tile, two are needed).  Mapping here:
+//   workgroup = 4 waves = one group of 16 points at a time (persistent over groups);
+//   MFMA "C layout": lane = (n = lane & 15: point, g = lane >> 4), VGPR r of output tile a holds
+//   feature j = 16a + 4g + r  ->  all four Taylor channels of a (point, feature) sit in ONE lane,
+//   so tanh and its derivative chain are lane-local;
+//   wave w owns output tiles a in {w, w+4} (7 tiles of 16 cover 100 features, 89 % dense);
+//   layer input  B[k][n]  = exchange tile T[k][n] (float4 = 4 channels; one ds_read_b128 serves the
+//                           four channel MFMAs of a k-step), written by all waves, barrier per layer;
+//   weights      A[j][k]  = the layer's matrix staged in LDS per layer ([k][112] floats, zero padded,
+//                           bias as row W), 45 KB: one conflict-free ds_read_b32 per (k-step, tile);
+//   stash (a, z_x, z_t, z_xx) goes to HBM in the generic kernels' layout
+//   S[(layer*W + feature)*s_pad + point] (6.4 KB per point at 4x100: 130 MB per evaluation of the
+//   reference configuration, ~50 us at HBM rate against >= 93 us of FP32 work).
+// Forward and reverse are two launches (the periodic-boundary seeds of the Schrodinger loss couple
+// pairs of points through the network outputs, inf_cont_schrodinger.py:107-129); they use the same
+// S / O buffers as k_forward / k_backward (kernels_generic.h), so either half can be swapped for its
+// generic counterpart -- which is how the tests pin them.
+//
+// Math: SURVEY.md Appendix A.
+#pragma once
+#include "kernels_fused20m.h"
+
+namespace pinn {
+
+template <int W>
+struct WideCfg {
+  static constexpr int NT = (W + 15) / 16;     // output tiles of 16 features
+  static constexpr int WP = NT * 16;           // padded width
+  static constexpr int KS = W / 4;             // k-steps of a W-long contraction
+  static constexpr int TP = 17;                // exchange-tile row pitch in float4 (16 points + 1 pad)
+  static constexpr int TILE = WP * TP;         // float4 per exchange tile
+  static constexpr int IMG = (W + 1) * WP;     // floats per staged matrix (W rows + bias row)
+  static_assert(W % 4 == 0 && W > 64 && W <= 128, "wide kernels serve 64 < W <= 128, W % 4 == 0");
+};
+
+// global weight image: per hidden dense layer d = 1..H-1 two matrices of IMG floats
+//   F_d[k][WP] = W_d[k][j]  (+ row W = b_d)     forward A operands
+//   R_d[j][WP] = W_d[k][j]                       reverse A operands (W_d^T)
+template <int W>
+inline size_t wide_image_floats(int n_hidden) { return (size_t)(n_hidden - 1) * 2 * WideCfg<W>::IMG; }
+template <int W>
+inline size_t wide_lds_bytes() { return (size_t)WideCfg<W>::IMG * 4 + (size_t)2 * WideCfg<W>::TILE * 16; }
+
+__device__ __forceinline__ void pack_store_wide(const NetDesc& nd, float* __restrict__ img, int i, float v) {
+  const int W = nd.width, WP = (W + 15) / 16 * 16, IMG = (W + 1) * WP;
+  const int lo = nd.off_w[1], hi = nd.off_w[nd.n_hidden];
+  if (i < lo || i >= hi) return;
+  const int per = W * W + W;
+  const int d1 = (i - lo) / per, rem = (i - lo) - d1 * per;
+  float* __restrict__ F = img + (size_t)d1 * 2 * IMG;
+  float* __restrict__ Rm = F + IMG;
+  if (rem < W * W) {
+    const int k = rem / W, j = rem - k * W;
+    F[k * WP + j] = v;
+    Rm[j * WP + k] = v;
+  } else {
+    F[W * WP + rem - W * W] = v;
+  }
+}
+
+// Called by every kernel that writes a weight: mirrors flat parameter i into whichever packed
+// image the engine keeps for the active loss+grad kernel.
+__device__ __forceinline__ void pack_store_any(const NetDesc& nd, float* __restrict__ img, int i, float v) {
+  if (!img) return;
+  if (nd.img_kind == 1) pack_store_m(nd, img, i, v);
+  else if (nd.img_kind == 2) pack_store_wide(nd, img, i, v);
+}
+
+// stage one IMG-float matrix into LDS (all 256 threads, 16-byte copies)
+template <int W>
+__device__ __forceinline__ void wide_stage(float* __restrict__ wl, const float* __restrict__ src) {
+  constexpr int NV = WideCfg<W>::IMG / 4;
+  for (int i = threadIdx.x; i < NV; i += 256)
+    reinterpret_cast<v4f*>(wl)[i] = reinterpret_cast<const v4f*>(src)[i];
+}
+
+// acc[t][c] += sum_k A[k][16 a_t + m] * Tin_c[k][n] for this wave's tiles a_t = wave + 4t
+template <int W>
+__device__ __forceinline__ void wide_gemm(acc4 (&acc)[2][4], const float* __restrict__ wl,
+                                          const v4f* __restrict__ Tin, const int wave, const int lane) {
+  using C = WideCfg<W>;
+  const int n = lane & 15, g = lane >> 4;
+  const bool two = wave + 4 < C::NT;
+  const float* __restrict__ a0 = wl + g * C::WP + 16 * wave + n;
+  const float* __restrict__ a1 = a0 + 64;
+  const v4f* __restrict__ b = Tin + g * C::TP + n;
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    const v4f B = b[4 * s * C::TP];
+    const float A0 = a0[4 * s * C::WP];
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.x, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.y, acc[0][1], 0, 0, 0);
+    acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.z, acc[0][2], 0, 0, 0);
+    acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.w, acc[0][3], 0, 0, 0);
+    if (two) {
+      const float A1 = a1[4 * s * C::WP];
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.y, acc[1][1], 0, 0, 0);
+      acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.z, acc[1][2], 0, 0, 0);
+      acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.w, acc[1][3], 0, 0, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward sweep over points [base, base + 16*n_groups): fills S (stash) and O (outputs) exactly as
+// k_forward does.
+// ---------------------------------------------------------------------------------------------
+template <int W, int NO>
+__global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __restrict__ th,
+                                                  const float* __restrict__ img,
+                                                  const float* __restrict__ xs,
+                                                  const float* __restrict__ ts, int base, int n_pad,
+                                                  int s_pad, int n_groups, float lbx, float lbt,
+                                                  float sx, float st, vec4<float>* __restrict__ S,
+                                                  vec4<float>* __restrict__ O) {
+  using C = WideCfg<W>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  v4f* const T0 = reinterpret_cast<v4f*>(wl + C::IMG);
+  v4f* const T1 = T0 + C::TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int H = nd.n_hidden;
+  v4f* const Sv = reinterpret_cast<v4f*>(S);
+  v4f* const Ov = reinterpret_cast<v4f*>(O);
+
+  // layer-0 parameters of this lane's features (tile t, register r): j = 16 (wave + 4t) + 4g + r
+  float w0x[2][4], w0t[2][4], b0[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * (wave + 4 * t) + 4 * g + r;
+      const bool ok = j < W;
+      w0x[t][r] = ok ? th[nd.off_w[0] + j] : 0.0f;
+      w0t[t][r] = ok ? th[nd.off_w[0] + W + j] : 0.0f;
+      b0[t][r] = ok ? th[nd.off_b[0] + j] : 0.0f;
+    }
+  // output layer (wave 0): A[m][k] = WL[k][m] for m < NO
+  float aL[C::KS];
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) aL[s] = n < NO ? th[nd.off_w[H] + (4 * s + g) * NO + n] : 0.0f;
+  }
+  const float bL0 = th[nd.off_b[H]], bL1 = NO > 1 ? th[nd.off_b[H] + 1] : 0.0f;
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int lp = grp * 16 + n, pt = base + lp;
+    const float x = xs[pt], t = ts[pt];
+    const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t - lbt, -1.0f);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int a = wave + 4 * tt;
+      if (a < C::NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * a + 4 * g + r;
+          const float z = fmaf(hx, w0x[tt][r], fmaf(ht, w0t[tt][r], b0[tt][r]));
+          const v4f s{j < W ? tanh_r5(z) : 0.0f, sx * w0x[tt][r], st * w0t[tt][r], 0.0f};
+          if (j < W) Sv[(size_t)j * s_pad + lp] = s;
+          T0[j * C::TP + n] = channels4(s);
+        }
+      }
+    }
+    // (the barrier that publishes T0 is the one after the first weight staging below)
+    v4f* Tin = T0;
+    v4f* Tout = T1;
+    for (int d = 1; d < H; ++d) {
+      wide_stage<W>(wl, img + (size_t)(d - 1) * 2 * C::IMG);
+      __syncthreads();
+      acc4 acc[2][4];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int a = (wave + 4 * tt < C::NT) ? wave + 4 * tt : wave;
+        acc[tt][0] = *reinterpret_cast<const v4f*>(wl + W * C::WP + 16 * a + 4 * g);   // bias b_d[j]
+        acc[tt][1] = acc[tt][2] = acc[tt][3] = acc4{0, 0, 0, 0};
+      }
+      wide_gemm<W>(acc, wl, Tin, wave, lane);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int a = wave + 4 * tt;
+        if (a < C::NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * a + 4 * g + r;
+            const v4f s{tanh_r5(acc[tt][0][r]), acc[tt][1][r], acc[tt][2][r], acc[tt][3][r]};
+            if (j < W) Sv[((size_t)d * W + j) * s_pad + lp] = s;
+            Tout[j * C::TP + n] = channels4(s);          // padded features: exact zeros
+          }
+        }
+      }
+      __syncthreads();            // Tout published; every wave is done with wl and Tin
+      v4f* tmp = Tin; Tin = Tout; Tout = tmp;
+    }
+    if (wave == 0) {              // linear output layer: rows m < NO of one 16-row tile
+      acc4 ao[4];
+      ao[0] = acc4{g == 0 ? bL0 : 0.0f, g == 0 ? bL1 : 0.0f, 0, 0};
+      ao[1] = ao[2] = ao[3] = acc4{0, 0, 0, 0};
+      const v4f* __restrict__ b = Tin + g * C::TP + n;
+#pragma unroll
+      for (int s = 0; s < C::KS; ++s) {
+        const v4f B = b[4 * s * C::TP];
+        ao[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.x, ao[0], 0, 0, 0);
+        ao[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.y, ao[1], 0, 0, 0);
+        ao[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.z, ao[2], 0, 0, 0);
+        ao[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.w, ao[3], 0, 0, 0);
+      }
+      if (g == 0) {
+        Ov[pt] = v4f{ao[0][0], ao[1][0], ao[2][0], ao[3][0]};
+        if (NO > 1) Ov[(size_t)n_pad + pt] = v4f{ao[0][1], ao[1][1], ao[2][1], ao[3][1]};
+      }
+    }
+    __syncthreads();              // the next group's first layer overwrites T0
+  }
+}
+
+}  // namespace pinn
