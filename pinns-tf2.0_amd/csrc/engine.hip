@@ -148,7 +148,8 @@ static bool fused_regs_ok(const pinn_ctx* c) {
 
 // the wide MFMA sweeps: float32, hidden width 100, two outputs (the Schrodinger net)
 static bool wide_ok(const pinn_ctx* c) {
-  return c->dtype == PINN_F32 && c->nd.width == 100 && c->nd.n_out == 2 && c->nd.n_hidden >= 2;
+  return c->dtype == PINN_F32 && c->nd.width == 100 && c->nd.n_out == 2 && c->nd.n_hidden == 4 &&
+         c->pde == PINN_PDE_SCHRODINGER;
 }
 
 template <typename T>
@@ -223,7 +224,8 @@ static int ensure_sets(pinn_ctx* c) {
   // the fused kernel keeps the whole set's stash (one launch); the generic path works in chunks
   const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
   c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (path 2)
-  const size_t rows = c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
+  const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
+  const size_t rows = c->path == 3 ? (size_t)wide_wg : c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
   const size_t need_S = c->path == 2 ? 16 : H * W * stash_pts * 4 * rs;
   const size_t need_Z = c->path == 2 ? 16 : W * (size_t)c->chunk * 4 * rs;
   const size_t need_part = rows * c->R * rs;
@@ -298,6 +300,27 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
                          sd.n_pad, c->chunk, lbx, lbt, sx, st, (vec4<real>*)c->S,
                          (vec4<real>*)c->O);
       if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
+      bool bwd_done = false;
+      if constexpr (sizeof(real) == 4 && PDE == 2) {
+        if (c->path == 3) {
+          static bool attr = false;
+          if (!attr) {
+            HIPCHK(hipFuncSetAttribute((const void*)k_wide_bwd<100, 2, 2, 4>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<100>()));
+            attr = true;
+          }
+          const int n_groups = pts / 16;
+          const int wg = n_groups < c->n_cu ? n_groups : c->n_cu;
+          hipLaunchKernelGGL((k_wide_bwd<100, 2, 2, 4>), dim3(wg), dim3(256), wide_lds_bytes<100>(), c->stream,
+                             c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+                             (const float*)c->ts, (const float*)c->tgt, base, sd.n_pad, c->chunk, n_groups,
+                             (float)lbx, (float)lbt, (float)sx, (float)st, (float)c->nu,
+                             (const vec4<float>*)c->S, (const vec4<float>*)c->O, (float*)c->part, c->R,
+                             ci > 0 ? 1 : 0);
+          bwd_done = true;
+        }
+      }
+      if (!bwd_done)
       hipLaunchKernelGGL((k_backward<real, PDE, KT>), grid, block, 0, c->stream, c->nd, sd,
                          (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts,
                          (const real*)c->tgt, base, sd.n_pad, c->chunk, lbx, lbt, sx, st,
@@ -307,7 +330,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     }
   }
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
-  const int n_rows = c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
+  const int n_rows = c->path == 3 ? ((c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu)
+                   : c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
   const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
   if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,

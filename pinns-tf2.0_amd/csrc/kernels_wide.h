@@ -90,7 +90,7 @@ __device__ __forceinline__ void wide_gemm(acc4 (&acc)[2][4], const float* __rest
   const float* __restrict__ a0 = wl + g * C::WP + 16 * wave + n;
   const float* __restrict__ a1 = a0 + 64;
   const v4f* __restrict__ b = Tin + g * C::TP + n;
-#pragma unroll
+#pragma unroll 5                                  // bounded: a full unroll hoists every operand and spills
   for (int s = 0; s < C::KS; ++s) {
     const v4f B = b[4 * s * C::TP];
     const float A0 = a0[4 * s * C::WP];
@@ -220,6 +220,247 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
     }
     __syncthreads();              // the next group's first layer overwrites T0
   }
+}
+
+// sum over the 16 lanes of a DPP row (the 16 points of a group); every lane of the row gets it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<DPP_QUAD_XOR1>(v);
+  v += dpp_mov<DPP_QUAD_XOR2>(v);
+  v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_ROW_MIRROR>(v);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reverse sweep over points [base, base + 16*n_groups), consuming S and O of the forward sweep:
+// seeds (point_seeds, kernels_generic.h), adjoints through every layer, all weight gradients.
+//   rev GEMM   in_bar[k][n] = sum_j W_d[k][j] z_bar[j][n]: the same wide_gemm on the staged W_d^T;
+//   dW_d       49 output tiles (k-tile x j-tile, bias = the constant ones row k = W of the input
+//              tile) x 16 MFMAs over the group's 64 (point, channel) rows, dealt round-robin to the
+//              four waves; the accumulators (13 tiles x 3 layers = 156 registers) stay resident
+//              across groups, and so do the per-lane partial sums of the first / last layer;
+//   output     one partial-gradient row per workgroup (same `part` format as the other kernels).
+// ---------------------------------------------------------------------------------------------
+template <int W, int NO, int PDE, int H>
+__global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const float* __restrict__ th,
+                                                  const float* __restrict__ img,
+                                                  const float* __restrict__ xs,
+                                                  const float* __restrict__ ts,
+                                                  const float* __restrict__ tgt, int base, int n_pad,
+                                                  int s_pad, int n_groups, float lbx, float lbt,
+                                                  float sx, float st, float nu,
+                                                  const vec4<float>* __restrict__ S,
+                                                  const vec4<float>* __restrict__ O,
+                                                  float* __restrict__ part, int R, int accumulate) {
+  using C = WideCfg<W>;
+  constexpr int NTT = C::NT * C::NT;              // dW tiles per layer
+  constexpr int NQ = (NTT + 3) / 4;               // tiles per wave (round-robin)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* const wl = reinterpret_cast<float*>(lds_raw);
+  v4f* const TI = reinterpret_cast<v4f*>(wl + C::IMG);
+  v4f* const TZ = TI + C::TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const v4f* const Sv = reinterpret_cast<const v4f*>(S);
+  float* __restrict__ row = part + (size_t)blockIdx.x * R;
+
+  float c1 = 1.0f, c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = __expf(th[nd.n_net + 1]); }
+  // output-layer weights of this lane's features
+  float wLo[2][4][NO];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * (wave + 4 * t) + 4 * g + r;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) wLo[t][r][o] = j < W ? th[nd.off_w[H] + j * NO + o] : 0.0f;
+    }
+
+  // accumulators that live across groups
+  acc4 dwacc[H - 1][NQ];                          // [d - 1][q]
+#pragma unroll
+  for (int d = 0; d < H - 1; ++d)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) dwacc[d][q] = acc4{0, 0, 0, 0};
+  float g0x[2][4], g0t[2][4], g0b[2][4], gWL[2][4][NO];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      g0x[t][r] = g0t[t][r] = g0b[t][r] = agpr_put(0.0f);      // parked in AGPRs between groups
+#pragma unroll
+      for (int o = 0; o < NO; ++o) gWL[t][r][o] = agpr_put(0.0f);
+    }
+  float gbL[NO], lsum[3] = {0, 0, 0}, dlsum[2] = {0, 0};
+#pragma unroll
+  for (int o = 0; o < NO; ++o) gbL[o] = 0.0f;
+
+  auto feat = [&](int t, int r) { return 16 * (wave + 4 * t) + 4 * g + r; };
+  auto load_stash = [&](v4f (&dst)[2][4], int d, int lp) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = feat(t, r);
+        dst[t][r] = j < W ? Sv[((size_t)d * W + j) * s_pad + lp] : v4f{0, 0, 0, 0};
+      }
+  };
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int lp = grp * 16 + n, pt = base + lp;
+    const float x = xs[pt], t_ = ts[pt];
+    const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t_ - lbt, -1.0f);
+    v4f s_cur[2][4], s_prev[2][4];
+    load_stash(s_cur, H - 1, lp);
+    load_stash(s_prev, H - 2, lp);
+
+    vec4<float> sbv[2];
+    float lt[3], dl[2];
+    point_seeds<float, PDE>(sd, pt, n_pad, O, tgt, c1, c2, sbv, lt, dl);
+    v4f sb[2];
+    sb[0] = v4f{sbv[0].x, sbv[0].y, sbv[0].z, sbv[0].w};
+    sb[1] = v4f{sbv[1].x, sbv[1].y, sbv[1].z, sbv[1].w};
+    if (g == 0) {
+      lsum[0] += lt[0]; lsum[1] += lt[1]; lsum[2] += lt[2];
+      dlsum[0] += dl[0]; dlsum[1] += dl[1];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) gbL[o] += sb[o].x;
+    }
+    // dense H (linear): z_bar = seeds; adjoint of this lane's layer-(H-1) outputs
+    v4f ob[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const v4f in = channels4(s_cur[t][r]);
+        v4f a = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          gWL[t][r][o] = agpr_put(agpr_get(gWL[t][r][o]) +
+                                  fmaf(in.w, sb[o].w, fmaf(in.z, sb[o].z, fmaf(in.y, sb[o].y, in.x * sb[o].x))));
+          a += sb[o] * wLo[t][r][o];
+        }
+        ob[t][r] = a;
+      }
+
+#pragma unroll
+    for (int d = H - 1; d >= 1; --d) {
+      wide_stage<W>(wl, img + (size_t)(d - 1) * 2 * C::IMG + C::IMG);       // W_d^T
+      // phase A: publish z_bar (layer d) and the layer-(d-1) output channels of this lane's features
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int a = wave + 4 * t;
+        if (a < C::NT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * a + 4 * g + r;
+            TZ[j * C::TP + n] = j < W ? preact_adjoint4(s_cur[t][r], ob[t][r]) : v4f{0, 0, 0, 0};
+            TI[j * C::TP + n] = j < W ? channels4(s_prev[t][r]) : (j == W ? v4f{1, 0, 0, 0} : v4f{0, 0, 0, 0});
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_cur[t][r] = s_prev[t][r];
+      if (d >= 2) load_stash(s_prev, d - 2, lp);        // in flight during phase B
+      __syncthreads();
+      // phase B: adjoint of the layer-(d-1) outputs, own tiles
+      acc4 acc[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = acc4{0, 0, 0, 0};
+      wide_gemm<W>(acc, wl, TZ, wave, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ob[t][r] = v4f{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+      // dW_d tiles tau = wave + 4q: rows k = 16 ti + ., columns j = 16 tj + .
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int tau = wave + 4 * q;
+        if (tau < NTT) {
+          const int ti = tau / C::NT, tj = tau - ti * C::NT;
+          const v4f* __restrict__ pa = TI + (16 * ti + n) * C::TP + g;
+          const v4f* __restrict__ pb = TZ + (16 * tj + n) * C::TP + g;
+          acc4 a = dwacc[d - 1][q];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const v4f A = pa[4 * s4], B = pb[4 * s4];
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, B.x, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, B.y, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, B.z, a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, B.w, a, 0, 0, 0);
+          }
+          dwacc[d - 1][q] = a;
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keep one tile's operands live at a time
+      }
+      __syncthreads();            // every wave is done with wl, TI, TZ
+    }
+    // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st); s_cur now holds the layer-0 stash
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const v4f zb = feat(t, r) < W ? preact_adjoint4(s_cur[t][r], ob[t][r]) : v4f{0, 0, 0, 0};
+        g0x[t][r] = agpr_put(agpr_get(g0x[t][r]) + fmaf(hx, zb.x, sx * zb.y));
+        g0t[t][r] = agpr_put(agpr_get(g0t[t][r]) + fmaf(ht, zb.x, st * zb.z));
+        g0b[t][r] = agpr_put(agpr_get(g0b[t][r]) + zb.x);
+      }
+  }
+
+  // ---- one partial-gradient row per workgroup
+  auto put = [&](int idx, float v) { row[idx] = accumulate ? row[idx] + v : v; };
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = feat(t, r);
+      const float a = row16_sum(agpr_get(g0x[t][r])), b = row16_sum(agpr_get(g0t[t][r])),
+                  c = row16_sum(agpr_get(g0b[t][r]));
+      float e[NO];
+#pragma unroll
+      for (int o = 0; o < NO; ++o) e[o] = row16_sum(agpr_get(gWL[t][r][o]));
+      if (n == 0 && j < W) {
+        put(nd.off_w[0] + j, a); put(nd.off_w[0] + W + j, b); put(nd.off_b[0] + j, c);
+#pragma unroll
+        for (int o = 0; o < NO; ++o) put(nd.off_w[H] + j * NO + o, e[o]);
+      }
+    }
+  if (wave == 0) {
+    float v3[3], vb[NO], vd[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v3[i] = row16_sum(lsum[i]);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) vb[o] = row16_sum(gbL[o]);
+    vd[0] = row16_sum(dlsum[0]); vd[1] = row16_sum(dlsum[1]);
+    if (lane == 0) {
+      put(nd.n_theta + 0, v3[0]); put(nd.n_theta + 1, v3[1]); put(nd.n_theta + 2, v3[2]);
+#pragma unroll
+      for (int o = 0; o < NO; ++o) put(nd.off_b[H] + o, vb[o]);
+      if (PDE == 1) { put(nd.n_net, vd[0]); put(nd.n_net + 1, vd[1]); }
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < H; ++d)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int tau = wave + 4 * q;
+      if (tau < NTT) {
+        const int ti = tau / C::NT, tj = tau - ti * C::NT;
+        const int j = 16 * tj + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * ti + 4 * g + r;
+          if (j < W && k < W) put(nd.off_w[d] + k * W + j, dwacc[d - 1][q][r]);
+          else if (j < W && k == W) put(nd.off_b[d] + j, dwacc[d - 1][q][r]);
+        }
+      }
+    }
 }
 
 }  // namespace pinn
