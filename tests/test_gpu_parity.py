@@ -219,3 +219,51 @@ def test_schrodinger_eval(schrodinger_sets, dtype, tag, N_f):
     assert np.max(np.abs(uv[::517, 0] - g["u_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
     assert np.max(np.abs(uv[::517, 1] - g["v_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
     eng.close()
+
+
+@pytest.mark.parametrize("N_f", [1024, 50000])
+def test_schrodinger_wide_mfma_sweeps_match_generic_and_oracle(schrodinger_sets, N_f):
+    """path 3 (k_wide_fwd / k_wide_bwd: every contraction on v_mfma_f32_16x16x4) against the generic
+    kernels and the oracle; 50000 collocation points = more 16-point groups than workgroups and more
+    than one 32768-point chunk (row accumulation across chunks)."""
+    from oracle import init, pde
+    from pinn_native import Engine
+    r = schrodinger_sets(50, 50, N_f)
+    X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
+    layers = [2, 100, 100, 100, 100, 2]
+    X_lb = np.concatenate((0 * tb + lb[0], tb), 1)
+    X_ub = np.concatenate((0 * tb + ub[0], tb), 1)
+    uv0 = np.concatenate([u0, v0], 1)
+    eng = Engine(layers, lb, ub, pde="schrodinger", dtype="f32")
+    assert eng.kernel_path() == 3
+    eng.set_collocation(X_f)
+    eng.set_boundary(X_lb, X_ub)
+    eng.set_data(X0, uv0)
+    rs = np.random.RandomState(5)
+    w = init.glorot_flat(layers)
+    w = w + 0.02 * rs.standard_normal(w.size)            # non-zero biases
+    eng.set_weights(w)
+    loss3, grad3, terms3 = eng.loss_grad()
+    loss3b, grad3b, _ = eng.loss_grad()
+    assert loss3b == loss3 and np.array_equal(grad3b, grad3)          # bit-reproducible
+    eng.set_kernel_path(0)
+    loss0, grad0, terms0 = eng.loss_grad()
+    assert abs(loss3 - loss0) / loss0 < TOL["f32"]["loss"]
+    assert rel(grad3, grad0) < TOL["f32"]["grad"]
+    assert np.max(np.abs(terms3 - terms0)) < 1e-5 * max(np.max(np.abs(terms0)), 1e-30) + 1e-9
+    if N_f <= 4096:
+        lo, go, _ = pde.schrodinger_loss_grad(w, layers, lb, ub, X_f, X_lb, X_ub, X0, uv0)
+        assert abs(loss3 - lo) / lo < TOL["f32"]["loss"]
+        assert rel(grad3, go) < TOL["f32"]["grad"]
+    # a few optimiser steps keep the packed weight image in sync with the flat vector
+    eng.set_kernel_path(3)
+    eng.adam_init(1e-3, 0.9, 0.999, 1e-7)
+    l3 = eng.adam_run(3)
+    w3 = eng.get_weights()
+    eng.set_weights(w)
+    eng.set_kernel_path(0)
+    eng.adam_init(1e-3, 0.9, 0.999, 1e-7)
+    l0 = eng.adam_run(3)
+    assert np.max(np.abs(l3 - l0) / l0) < 1e-4
+    assert rel(w3, eng.get_weights()) < 1e-4
+    eng.close()
