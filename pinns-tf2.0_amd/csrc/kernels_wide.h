@@ -35,7 +35,9 @@ struct WideCfg {
   static constexpr int KS = W / 4;             // k-steps of a W-long contraction
   static constexpr int TP = 17;                // exchange-tile row pitch in float4 (16 points + 1 pad)
   static constexpr int TILE = WP * TP;         // float4 per exchange tile
-  static constexpr int IMG = (W + 1) * WP;     // floats per staged matrix (W rows + bias row)
+  static constexpr int IMG_RAW = (W + 1) * WP;  // floats per matrix (W rows + bias row)
+  static constexpr int NCH = (IMG_RAW + 255) / 256;   // 1 KiB LDS-DMA pieces per matrix
+  static constexpr int IMG = NCH * 256;         // floats per staged matrix, padded to whole pieces
   static_assert(W % 4 == 0 && W > 64 && W <= 128, "wide kernels serve 64 < W <= 128, W % 4 == 0");
 };
 
@@ -45,10 +47,10 @@ struct WideCfg {
 template <int W>
 inline size_t wide_image_floats(int n_hidden) { return (size_t)(n_hidden - 1) * 2 * WideCfg<W>::IMG; }
 template <int W>
-inline size_t wide_lds_bytes() { return (size_t)WideCfg<W>::IMG * 4 + (size_t)2 * WideCfg<W>::TILE * 16; }
+inline size_t wide_lds_bytes() { return (size_t)2 * WideCfg<W>::IMG * 4 + (size_t)2 * WideCfg<W>::TILE * 16; }
 
 __device__ __forceinline__ void pack_store_wide(const NetDesc& nd, float* __restrict__ img, int i, float v) {
-  const int W = nd.width, WP = (W + 15) / 16 * 16, IMG = (W + 1) * WP;
+  const int W = nd.width, WP = (W + 15) / 16 * 16, IMG = ((W + 1) * WP + 255) / 256 * 256;
   const int lo = nd.off_w[1], hi = nd.off_w[nd.n_hidden];
   if (i < lo || i >= hi) return;
   const int per = W * W + W;
@@ -72,40 +74,63 @@ __device__ __forceinline__ void pack_store_any(const NetDesc& nd, float* __restr
   else if (nd.img_kind == 2) pack_store_wide(nd, img, i, v);
 }
 
-// stage one IMG-float matrix into LDS (all 256 threads, 16-byte copies)
+// Asynchronous global -> LDS copy of one matrix (global_load_lds_dwordx4: each wave-instruction
+// moves 1 KiB, destination = wave-uniform base + lane * 16, no registers involved).  The copy of
+// the NEXT layer's matrix is issued right after a layer's opening barrier and lands in the other
+// LDS buffer while the MFMAs of the current layer run; the issuing wave drains it with
+// s_waitcnt vmcnt(0) just before the next opening barrier.
 template <int W>
-__device__ __forceinline__ void wide_stage(float* __restrict__ wl, const float* __restrict__ src) {
-  constexpr int NV = WideCfg<W>::IMG / 4;
-  for (int i = threadIdx.x; i < NV; i += 256)
-    reinterpret_cast<v4f*>(wl)[i] = reinterpret_cast<const v4f*>(src)[i];
+__device__ __forceinline__ void wide_dma(float* __restrict__ wl_dst, const float* __restrict__ src,
+                                         const int wave, const int lane) {
+  using C = WideCfg<W>;
+  for (int c = wave; c < C::NCH; c += 4)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + c * 256 + lane * 4),
+        (__attribute__((address_space(3))) void*)(wl_dst + c * 256), 16, 0, 0);
 }
+// The DMA is drained (s_waitcnt vmcnt(0)) right after the MFMA block it ran under -- by then it is
+// long done and the stash stores of the previous layer are too, so the wait is free -- and NOT at
+// the barriers, which would also wait for the acknowledgement of the stash stores just issued.
+__device__ __forceinline__ void wide_dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// acc[t][c] += sum_k A[k][16 a_t + m] * Tin_c[k][n] for this wave's tiles a_t = wave + 4t
-template <int W>
-__device__ __forceinline__ void wide_gemm(acc4 (&acc)[2][4], const float* __restrict__ wl,
-                                          const v4f* __restrict__ Tin, const int wave, const int lane) {
+// acc[t][c] += sum_k A[k][16 a_t + m] * Tin_c[k][n] for this wave's tiles a_t = wave + 4t, t < NTW.
+// Straight-line over the k-steps (no branch inside: the accumulators must stay in the MFMA
+// register file), operands of step s+1 fetched before the eight MFMAs of step s are issued.
+template <int W, int NTW>
+__device__ __forceinline__ void wide_gemm_n(acc4 (&acc)[2][4], const float* __restrict__ wl,
+                                            const v4f* __restrict__ Tin, const int wave, const int lane) {
   using C = WideCfg<W>;
   const int n = lane & 15, g = lane >> 4;
-  const bool two = wave + 4 < C::NT;
   const float* __restrict__ a0 = wl + g * C::WP + 16 * wave + n;
-  const float* __restrict__ a1 = a0 + 64;
   const v4f* __restrict__ b = Tin + g * C::TP + n;
-#pragma unroll 5                                  // bounded: a full unroll hoists every operand and spills
+  v4f Bn = b[0];
+  float A0n = a0[0], A1n = NTW > 1 ? a0[64] : 0.0f;
+#pragma unroll
   for (int s = 0; s < C::KS; ++s) {
-    const v4f B = b[4 * s * C::TP];
-    const float A0 = a0[4 * s * C::WP];
+    const v4f B = Bn;
+    const float A0 = A0n, A1 = A1n;
+    if (s + 1 < C::KS) {
+      Bn = b[4 * (s + 1) * C::TP];
+      A0n = a0[4 * (s + 1) * C::WP];
+      if (NTW > 1) A1n = a0[4 * (s + 1) * C::WP + 64];
+    }
     acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.x, acc[0][0], 0, 0, 0);
     acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.y, acc[0][1], 0, 0, 0);
     acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.z, acc[0][2], 0, 0, 0);
     acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0, B.w, acc[0][3], 0, 0, 0);
-    if (two) {
-      const float A1 = a1[4 * s * C::WP];
+    if (NTW > 1) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.x, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.y, acc[1][1], 0, 0, 0);
       acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.z, acc[1][2], 0, 0, 0);
       acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1, B.w, acc[1][3], 0, 0, 0);
     }
   }
+}
+template <int W>
+__device__ __forceinline__ void wide_gemm(acc4 (&acc)[2][4], const float* __restrict__ wl,
+                                          const v4f* __restrict__ Tin, const int wave, const int lane) {
+  if (wave + 4 < WideCfg<W>::NT) wide_gemm_n<W, 2>(acc, wl, Tin, wave, lane);   // wave-uniform
+  else wide_gemm_n<W, 1>(acc, wl, Tin, wave, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -122,8 +147,8 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
                                                   vec4<float>* __restrict__ O) {
   using C = WideCfg<W>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  float* const wl = reinterpret_cast<float*>(lds_raw);
-  v4f* const T0 = reinterpret_cast<v4f*>(wl + C::IMG);
+  float* const wbuf = reinterpret_cast<float*>(lds_raw);           // two weight buffers of IMG floats
+  v4f* const T0 = reinterpret_cast<v4f*>(wbuf + 2 * C::IMG);
   v4f* const T1 = T0 + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,6 +156,9 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
   const int H = nd.n_hidden;
   v4f* const Sv = reinterpret_cast<v4f*>(S);
   v4f* const Ov = reinterpret_cast<v4f*>(O);
+  int wcur = 0;                                                    // buffer holding the matrix about to be used
+  wide_dma<W>(wbuf, img, wave, lane);                              // F_1
+  wide_dma_drain();
 
   // layer-0 parameters of this lane's features (tile t, register r): j = 16 (wave + 4t) + 4g + r
   float w0x[2][4], w0t[2][4], b0[2][4];
@@ -144,9 +172,9 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
       w0t[t][r] = ok ? th[nd.off_w[0] + W + j] : 0.0f;
       b0[t][r] = ok ? th[nd.off_b[0] + j] : 0.0f;
     }
-  // output layer (wave 0): A[m][k] = WL[k][m] for m < NO
+  // output layer (wave 3: it owns a single feature tile): A[m][k] = WL[k][m] for m < NO
   float aL[C::KS];
-  if (wave == 0) {
+  if (wave == 3) {
 #pragma unroll
     for (int s = 0; s < C::KS; ++s) aL[s] = n < NO ? th[nd.off_w[H] + (4 * s + g) * NO + n] : 0.0f;
   }
@@ -170,12 +198,16 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
         }
       }
     }
-    // (the barrier that publishes T0 is the one after the first weight staging below)
     v4f* Tin = T0;
     v4f* Tout = T1;
     for (int d = 1; d < H; ++d) {
-      wide_stage<W>(wl, img + (size_t)(d - 1) * 2 * C::IMG);
-      __syncthreads();
+      lds_barrier();              // Tin published, F_d landed (drained below / in the prologue),
+                                  // nobody still reads the other weight buffer
+      const float* __restrict__ wl = wbuf + wcur * C::IMG;
+      {                           // next matrix on its way: F_{d+1}, or F_1 for the next group
+        const int dn = d + 1 < H ? d : 0;
+        wide_dma<W>(wbuf + (wcur ^ 1) * C::IMG, img + (size_t)dn * 2 * C::IMG, wave, lane);
+      }
       acc4 acc[2][4];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -184,6 +216,7 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
         acc[tt][1] = acc[tt][2] = acc[tt][3] = acc4{0, 0, 0, 0};
       }
       wide_gemm<W>(acc, wl, Tin, wave, lane);
+      wide_dma_drain();
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int a = wave + 4 * tt;
@@ -197,10 +230,11 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
           }
         }
       }
-      __syncthreads();            // Tout published; every wave is done with wl and Tin
+      wcur ^= 1;
       v4f* tmp = Tin; Tin = Tout; Tout = tmp;
     }
-    if (wave == 0) {              // linear output layer: rows m < NO of one 16-row tile
+    lds_barrier();                // last hidden layer's tile published
+    if (wave == 3) {              // linear output layer: rows m < NO of one 16-row tile
       acc4 ao[4];
       ao[0] = acc4{g == 0 ? bL0 : 0.0f, g == 0 ? bL1 : 0.0f, 0, 0};
       ao[1] = ao[2] = ao[3] = acc4{0, 0, 0, 0};
@@ -218,8 +252,9 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
         if (NO > 1) Ov[(size_t)n_pad + pt] = v4f{ao[0][1], ao[1][1], ao[2][1], ao[3][1]};
       }
     }
-    __syncthreads();              // the next group's first layer overwrites T0
+    lds_barrier();                // wave 3 is done with the last tile before the next group reuses it
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
 // sum over the 16 lanes of a DPP row (the 16 points of a group); every lane of the row gets it
@@ -256,14 +291,17 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
   constexpr int NTT = C::NT * C::NT;              // dW tiles per layer
   constexpr int NQ = (NTT + 3) / 4;               // tiles per wave (round-robin)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  float* const wl = reinterpret_cast<float*>(lds_raw);
-  v4f* const TI = reinterpret_cast<v4f*>(wl + C::IMG);
+  float* const wbuf = reinterpret_cast<float*>(lds_raw);           // two weight buffers of IMG floats
+  v4f* const TI = reinterpret_cast<v4f*>(wbuf + 2 * C::IMG);
   v4f* const TZ = TI + C::TILE;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const v4f* const Sv = reinterpret_cast<const v4f*>(S);
   float* __restrict__ row = part + (size_t)blockIdx.x * R;
+  int wcur = 0;
+  wide_dma<W>(wbuf, img + (size_t)(H - 2) * 2 * C::IMG + C::IMG, wave, lane);     // W_{H-1}^T
+  wide_dma_drain();
 
   float c1 = 1.0f, c2 = nu;
   if (PDE == 1) { c1 = th[nd.n_net]; c2 = __expf(th[nd.n_net + 1]); }
@@ -347,7 +385,6 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
 
 #pragma unroll
     for (int d = H - 1; d >= 1; --d) {
-      wide_stage<W>(wl, img + (size_t)(d - 1) * 2 * C::IMG + C::IMG);       // W_d^T
       // phase A: publish z_bar (layer d) and the layer-(d-1) output channels of this lane's features
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -365,8 +402,13 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_cur[t][r] = s_prev[t][r];
-      if (d >= 2) load_stash(s_prev, d - 2, lp);        // in flight during phase B
-      __syncthreads();
+      lds_barrier();              // TZ / TI published, W_d^T landed, the other weight buffer is free
+      const float* __restrict__ wl = wbuf + wcur * C::IMG;
+      {                           // next matrix on its way: W_{d-1}^T, or W_{H-1}^T for the next group
+        const int dn = d >= 2 ? d - 1 : H - 1;
+        wide_dma<W>(wbuf + (wcur ^ 1) * C::IMG, img + (size_t)(dn - 1) * 2 * C::IMG + C::IMG, wave, lane);
+        wcur ^= 1;
+      }
       // phase B: adjoint of the layer-(d-1) outputs, own tiles
       acc4 acc[2][4];
 #pragma unroll
@@ -378,28 +420,32 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) ob[t][r] = v4f{acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
-      // dW_d tiles tau = wave + 4q: rows k = 16 ti + ., columns j = 16 tj + .
+      // dW_d tiles tau = wave + 4q: rows k = 16 ti + ., columns j = 16 tj + .  No branch around the
+      // MFMAs (the accumulators must stay in the matrix register file): a wave whose last slot has
+      // no tile (tau >= 49) recomputes tile 48 there and the result is simply not stored.
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int tau = wave + 4 * q;
-        if (tau < NTT) {
-          const int ti = tau / C::NT, tj = tau - ti * C::NT;
-          const v4f* __restrict__ pa = TI + (16 * ti + n) * C::TP + g;
-          const v4f* __restrict__ pb = TZ + (16 * tj + n) * C::TP + g;
-          acc4 a = dwacc[d - 1][q];
+        const int tau = min(wave + 4 * q, NTT - 1);
+        const int ti = tau / C::NT, tj = tau - ti * C::NT;
+        const v4f* __restrict__ pa = TI + (16 * ti + n) * C::TP + g;
+        const v4f* __restrict__ pb = TZ + (16 * tj + n) * C::TP + g;
+        acc4 a = dwacc[d - 1][q];
+        v4f A[4], B[4];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            const v4f A = pa[4 * s4], B = pb[4 * s4];
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, B.x, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, B.y, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, B.z, a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, B.w, a, 0, 0, 0);
-          }
-          dwacc[d - 1][q] = a;
+        for (int s4 = 0; s4 < 4; ++s4) { A[s4] = pa[4 * s4]; B[s4] = pb[4 * s4]; }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].x, B[s4].x, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].y, B[s4].y, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].z, B[s4].z, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].w, B[s4].w, a, 0, 0, 0);
         }
+        dwacc[d - 1][q] = a;
         __builtin_amdgcn_sched_barrier(0);        // keep one tile's operands live at a time
       }
-      __syncthreads();            // every wave is done with wl, TI, TZ
+      wide_dma_drain();           // next matrix landed (issued a whole phase B ago)
+      if (d >= 2) load_stash(s_prev, d - 2, lp);
+      lds_barrier();              // every wave is done with TI, TZ and this layer's weights
     }
     // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st); s_cur now holds the layer-0 stash
 #pragma unroll
@@ -413,6 +459,7 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
       }
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
   // ---- one partial-gradient row per workgroup
   auto put = [&](int idx, float v) { row[idx] = accumulate ? row[idx] + v : v; };
 #pragma unroll
