@@ -423,25 +423,48 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
       // dW_d tiles tau = wave + 4q: rows k = 16 ti + ., columns j = 16 tj + .  No branch around the
       // MFMAs (the accumulators must stay in the matrix register file): a wave whose last slot has
       // no tile (tau >= 49) recomputes tile 48 there and the result is simply not stored.
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
+      auto tile_ptrs = [&](int q, const v4f*& pa, const v4f*& pb) {
         const int tau = min(wave + 4 * q, NTT - 1);
         const int ti = tau / C::NT, tj = tau - ti * C::NT;
-        const v4f* __restrict__ pa = TI + (16 * ti + n) * C::TP + g;
-        const v4f* __restrict__ pb = TZ + (16 * tj + n) * C::TP + g;
-        acc4 a = dwacc[d - 1][q];
-        v4f A[4], B[4];
+        pa = TI + (16 * ti + n) * C::TP + g;
+        pb = TZ + (16 * tj + n) * C::TP + g;
+      };
+      // two tiles at a time, their MFMAs alternating: each accumulator is then touched every 64
+      // cycles, above the 40-cycle dependent-issue latency of v_mfma_f32_16x16x4_f32
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) { A[s4] = pa[4 * s4]; B[s4] = pb[4 * s4]; }
+      for (int q = 0; q + 1 < NQ; q += 2) {
+        const v4f *pa0, *pb0, *pa1, *pb1;
+        tile_ptrs(q, pa0, pb0);
+        tile_ptrs(q + 1, pa1, pb1);
+        acc4 a0 = dwacc[d - 1][q], a1 = dwacc[d - 1][q + 1];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].x, B[s4].x, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].y, B[s4].y, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].z, B[s4].z, a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A[s4].w, B[s4].w, a, 0, 0, 0);
+          const v4f A0 = pa0[4 * s4], B0 = pb0[4 * s4], A1 = pa1[4 * s4], B1 = pb1[4 * s4];
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.x, B0.x, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.x, B1.x, a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.y, B0.y, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.y, B1.y, a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.z, B0.z, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.z, B1.z, a1, 0, 0, 0);
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(A0.w, B0.w, a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A1.w, B1.w, a1, 0, 0, 0);
         }
-        dwacc[d - 1][q] = a;
-        __builtin_amdgcn_sched_barrier(0);        // keep one tile's operands live at a time
+        dwacc[d - 1][q] = a0; dwacc[d - 1][q + 1] = a1;
+        __builtin_amdgcn_sched_barrier(0);        // keep one pair's operands live at a time
+      }
+      if (NQ & 1) {
+        const v4f *pa, *pb;
+        tile_ptrs(NQ - 1, pa, pb);
+        acc4 a = dwacc[d - 1][NQ - 1];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const v4f A = pa[4 * s4], B = pb[4 * s4];
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.x, B.x, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.y, B.y, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.z, B.z, a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x4f32(A.w, B.w, a, 0, 0, 0);
+        }
+        dwacc[d - 1][NQ - 1] = a;
       }
       wide_dma_drain();           // next matrix landed (issued a whole phase B ago)
       if (d >= 2) load_stash(s_prev, d - 2, lp);
