@@ -1,6 +1,9 @@
+"""Per-step timing of the non-headline BASELINE configs on one MI355X (Adam steps, inputs resident):
+cfg 3 identification (N_u = 10000), cfg 4 Schrodinger (N_f = 20000, 4x100), cfg 5 shard sizes of the
+1D Burgers N_f = 1e6 run.   python profiles/time_configs.py"""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path.insert(0, ROOT)
 import bench
 sys.path.insert(0, os.path.join(bench.PKG, "1dcomplex-schrodinger"))
