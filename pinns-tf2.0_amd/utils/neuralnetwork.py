@@ -110,6 +110,8 @@ class NeuralNetwork(object):
                 self.sizes_b.append(int(width if i != 0 else self.layers[1]))
 
         self._engine.set_weights(self._initial_weights(hp))
+        if hp.get("init_weights"):                   # resume from a checkpoint written by save_weights
+            self.load_weights(hp["init_weights"])
         self._engine.adam_init(self.tf_optimizer.learning_rate, self.tf_optimizer.beta_1,
                                self.tf_optimizer.beta_2, self.tf_optimizer.epsilon)
         self._bound = None
@@ -179,6 +181,18 @@ class NeuralNetwork(object):
 
     def set_weights(self, w):
         self._engine.set_weights(np.asarray(w, dtype=np.float64).ravel())
+
+    # ---- checkpointing (the reference has none; the flat vector IS the natural format) --
+    def save_weights(self, path):
+        """np.save of the float64 flat weight vector (reference layout, get_weights())."""
+        np.save(path, self.get_weights())
+        return path
+
+    def load_weights(self, path):
+        w = np.load(path)
+        if w.shape != (self._engine.n_params,):
+            raise ValueError("checkpoint holds %s values, the model has %d" % (w.shape, self._engine.n_params))
+        self.set_weights(w)
 
     def get_loss_and_flat_grad(self, X, u):
         self._bind(X, u)

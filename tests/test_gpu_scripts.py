@@ -85,3 +85,31 @@ def test_inf_cont_schrodinger_runs(tmp_path):
     assert len(rows) == 6 and end is not None and end[0] == 60
     assert all(r[2] == r[2] and r[2] < 10 for r in rows)                    # finite, sane losses
     assert rows[-1][2] < rows[0][2]
+
+
+def test_checkpoint_round_trip_is_bit_exact(tmp_path, monkeypatch):
+    """save_weights / load_weights / hp["init_weights"]: the float64 flat vector survives exactly and a
+    resumed model evaluates to the same loss"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(PKG, "utils"))
+    sys.path.insert(0, os.path.join(PKG, "1d-burgers"))
+    import importlib
+    monkeypatch.setattr(sys, "argv", ["inf_cont_burgers.py"])     # the script reads argv[1] as hp.json
+    burgersutil = importlib.import_module("burgersutil")
+    inf = importlib.import_module("inf_cont_burgers")
+    from logger import Logger
+    g = json.load(open(golden("burgers_default_run.json")))
+    hp = dict(g["hp"], N_f=2048, N_u=64, tf_epochs=5, nt_epochs=5, dtype="f64", log_frequency=1000)
+    np.random.seed(1234)
+    r = burgersutil.prep_data(os.path.join(PKG, "1d-burgers", "data", "burgers_shock.mat"), hp["N_u"], hp["N_f"], noise=0.0)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    log = Logger(hp)
+    log.set_error_fn(lambda: 0.0)                # as the reference: the script installs the error metric
+    a = inf.BurgersInformedNN(hp, log, X_f, ub, lb, nu=0.01 / np.pi)
+    a.fit(X_u, u)
+    ck = a.save_weights(str(tmp_path / "w.npy"))
+    la, _ = a.grad(X_u, u)
+    b = inf.BurgersInformedNN(dict(hp, init_weights=ck), Logger(hp), X_f, ub, lb, nu=0.01 / np.pi)
+    assert np.array_equal(a.get_weights(), b.get_weights())
+    lb_, _ = b.grad(X_u, u)
+    assert la == lb_
