@@ -1,3 +1,5 @@
+"""(profiling build) s_memtime phase timeline of k_lbc_coef:
+    PINN_HIP_LIB=pinns-tf2.0_amd/pinn_native/libpinn_hip_stamps.so python profiles/coef_stamps.py"""
 import os, sys, ctypes
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

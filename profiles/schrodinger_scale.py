@@ -1,3 +1,5 @@
+"""Wide (width-100) MFMA sweeps: forward / reverse kernel time vs number of 16-point groups per workgroup.
+    python profiles/schrodinger_scale.py"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
