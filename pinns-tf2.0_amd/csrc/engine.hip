@@ -102,7 +102,8 @@ struct pinn_ctx {
   size_t cap_loss_hist = 0;
 
   // L-BFGS
-  LbfgsState* lb_state = nullptr;
+  LbfgsState* lb_state = nullptr;    // two copies (double buffered, see k_lbc_coef_apply); lb_flip = current
+  int lb_flip = 0;
   double *lb_x = nullptr, *lb_d = nullptr, *lb_gold = nullptr, *lb_S = nullptr, *lb_Y = nullptr,
          *lb_ro = nullptr, *lb_al = nullptr, *lb_q = nullptr, *lb_log_loss = nullptr;
   int* lb_log_iter = nullptr;
@@ -619,7 +620,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   c->lb_ready = false;
   if (max_iter == 0) { c->lb_ready = true; return 0; }           // custom_lbfgs.py:43-44
   if (!c->lb_state) {
-    if (dev_alloc(&c->lb_state, sizeof(LbfgsState)) || dev_alloc(&c->lb_x, n * 8) ||
+    if (dev_alloc(&c->lb_state, 2 * sizeof(LbfgsState)) || dev_alloc(&c->lb_x, n * 8) ||
         dev_alloc(&c->lb_d, n * 8) || dev_alloc(&c->lb_gold, n * 8) || dev_alloc(&c->lb_q, n * 8))
       return PINN_EHIP;
   }
@@ -627,13 +628,16 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   c->lb_M1 = M1;
   // compact mode needs the two padded Gram matrices in LDS (<= 64 KiB) and one lane per slot
   c->lb_mode_active = (c->lb_mode == 1 && M1 <= LBC_MAXSLOTS) ? 1 : 0;
-  if (c->lb_mode_active && lbc_coef_lds_bytes(M1) > 64 * 1024)
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lbc_coef_lds_bytes(M1)));
+  if (c->lb_mode_active && lbc_coef_apply_lds_bytes(M1) > 64 * 1024) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lbc_coef_apply_lds_bytes(M1)));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lbc_coef_apply_lds_bytes(M1)));
+  }
   if (n_corr > c->lb_cap_corr) {
     if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
-        dev_alloc(&c->lb_ro, (size_t)M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
-        dev_alloc(&c->lb_SY, (size_t)M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)M1 * M1 * 8) ||
+        dev_alloc(&c->lb_ro, (size_t)2 * M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
+        dev_alloc(&c->lb_SY, (size_t)2 * M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)2 * M1 * M1 * 8) ||
         dev_alloc(&c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_cy, (size_t)M1 * 8) || dev_alloc(&c->lb_ex, sizeof(LbcExtra)))
       return PINN_EHIP;
@@ -643,8 +647,10 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   HIPCHK(hipMemsetAsync(c->lb_Y, 0, (size_t)M1 * n * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_cs, 0, (size_t)M1 * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_cy, 0, (size_t)M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)M1 * M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)M1 * M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)2 * M1 * M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)2 * M1 * M1 * 8, c->stream));
+  HIPCHK(hipMemsetAsync(c->lb_ro, 0, (size_t)2 * M1 * 8, c->stream));
+  c->lb_flip = 0;
   HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + LBC_NSCAL) * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->lb_ex, 0, sizeof(LbcExtra), c->stream));
   if (max_iter + 1 > c->lb_cap_log) {
@@ -660,7 +666,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   int rc = eval_loss_grad(c);                                      // :65
   if (rc) return rc;
   hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, (int)n, (int)n,
-                     max_iter, c->lb_max_eval, tol_fun, tol_x, c->lb_state, c->gl, c->lb_d,
+                     max_iter, c->lb_max_eval, tol_fun, tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_d,
                      c->lb_log_iter, c->lb_log_loss, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -679,41 +685,47 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     c->lb_iters_issued += 1;
     if (c->lb_mode_active) {
       const int M1 = c->lb_M1;
-      const size_t lsh = lbc_coef_lds_bytes(M1);
-      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, c->lb_state,
+      const size_t lsh = lbc_coef_apply_lds_bytes(M1);
+      LbfgsState* st_in = c->lb_state + c->lb_flip;
+      LbfgsState* st_out = c->lb_state + (c->lb_flip ^ 1);
+      const size_t mm = (size_t)M1 * M1;
+      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
                          c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
-      hipLaunchKernelGGL(k_lbc_coef, dim3(1), dim3(LBC_THREADS), lsh, c->stream, M1, c->lb_ncorr,
-                         c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun, c->lb_max_eval,
-                         c->lb_post_pending ? 1 : 0, n, c->lb_state, c->lb_ex, c->gl, c->lb_dots,
-                         c->lb_SY, c->lb_YY, c->lb_ro, c->lb_cs, c->lb_cy, c->lb_log_iter,
-                         c->lb_log_loss);
-      c->lb_post_pending = false;
       const dim3 agrid((n + 63) / 64);
-      if (c->dtype == PINN_F64)
-        hipLaunchKernelGGL((k_lbc_apply<double>), agrid, dim3(64 * LBA_SLICES), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (double*)c->theta_r, c->nd, c->img);
-      else
-        hipLaunchKernelGGL((k_lbc_apply<float>), agrid, dim3(64 * LBA_SLICES), 0, c->stream, n, M1, c->lb_state, c->lb_ex, c->gl, c->lb_S, c->lb_Y, c->lb_cs, c->lb_cy, c->lb_d, c->lb_gold, c->lb_x, c->theta, (float*)c->theta_r, c->nd, c->img);
+#define COEF_APPLY(REAL)                                                                           \
+      hipLaunchKernelGGL((k_lbc_coef_apply<REAL>), agrid, dim3(LBC_THREADS), lsh, c->stream, n, M1,   \
+                         c->lb_ncorr, c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun,           \
+                         c->lb_max_eval, c->lb_post_pending ? 1 : 0, n, st_in, st_out, c->gl,         \
+                         c->lb_dots, c->lb_SY + c->lb_flip * mm, c->lb_YY + c->lb_flip * mm,          \
+                         c->lb_ro + c->lb_flip * M1, c->lb_SY + (c->lb_flip ^ 1) * mm,                \
+                         c->lb_YY + (c->lb_flip ^ 1) * mm, c->lb_ro + (c->lb_flip ^ 1) * M1,          \
+                         c->lb_log_iter, c->lb_log_loss, c->lb_S, c->lb_Y, c->lb_d, c->lb_gold,       \
+                         c->lb_x, c->theta, (REAL*)c->theta_r, c->nd, c->img)
+      if (c->dtype == PINN_F64) COEF_APPLY(double); else COEF_APPLY(float);
+#undef COEF_APPLY
+      c->lb_post_pending = false;
+      c->lb_flip ^= 1;
     } else if (c->dtype == PINN_F64)
-      hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
+      hipLaunchKernelGGL((k_lbfgs_step<double>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_x, c->theta, (double*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     else
-      hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
+      hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
     int rc = eval_loss_grad(c);
     if (rc) return rc;
     if (c->lb_mode_active) { c->lb_post_pending = true; continue; }   // folded into the next k_lbc_coef
     hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
-                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state, c->gl, c->lb_d,
+                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_d,
                        c->lb_log_iter, c->lb_log_loss, 0);
   }
   if (c->lb_post_pending) {                       // the host is about to read the state: settle it
     hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
-                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state, c->gl, c->lb_d,
+                       c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_d,
                        c->lb_log_iter, c->lb_log_loss, 0);
     c->lb_post_pending = false;
   }
   HIPCHK(hipGetLastError());
   LbfgsState hs;
-  HIPCHK(hipMemcpyAsync(&hs, c->lb_state, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&hs, c->lb_state + c->lb_flip, sizeof hs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   const int fresh = hs.n_logged - c->lb_logged_read;
   if (fresh > 0 && iters && losses) {

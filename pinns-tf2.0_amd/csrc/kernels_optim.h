@@ -296,7 +296,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_post(
 //   k_lbc_dots   one workgroup per history slot: every dot product this iteration needs
 //                (s_a.y_c, s_c.y_a, y_a.y_c, s_a.g, y_a.g, y_c.s_c, y_c.y_c, g.g, |g|_1, |t d|_1) in
 //                parallel; also materialises the candidate pair s_c = t d, y_c = g - g_old.
-//   k_lbc_coef   (a) the bookkeeping/break tests of custom_lbfgs.py:185-224 for the evaluation
+//   k_lbc_coef_apply   (a) the bookkeeping/break tests of custom_lbfgs.py:185-224 for the evaluation
 //                that precedes this iteration (k_lbfgs_post folded in, `do_post`);
 //                (b) accepts the pair (y.s > 1e-10), maintains the Gram matrices
 //                SY[a][b] = s_a.y_b, YY[a][b] = y_a.y_b, and runs the two-loop recursion of
@@ -306,7 +306,8 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_post(
 //                turn comes, so a recursion step is: lane i finishes alpha_i -> broadcast ->
 //                every lane does one fma.  No cross-lane reductions inside the loops.
 //                Emits d = cg g + sum_j (cy_j y_j + cs_j s_j), gtd, the step t and the break flag.
-//   k_lbc_apply  d, g_old, x += t d (and the model weights when an evaluation follows).
+//                (c) d, g_old, x += t d (and the model weights when an evaluation follows), in
+//                the same launch: every workgroup repeats (a)-(b) and updates its own 64 weights.
 // Mathematically identical to the reference recursion; rounding differs at the 1e-16 level.
 // The ring has m+1 slots so that the candidate never overwrites a pair that may still be needed.
 // ---------------------------------------------------------------------------------------------
@@ -424,8 +425,14 @@ __device__ long long g_coef_stamps[16];         // s_memtime timeline of the las
 #endif
 inline int lbc_ld(int M1) { return M1 | 1; }     // odd leading dimension: column walks hit distinct banks
 constexpr int LBC_MAXSLOTS = 62;                  // one lane per ring slot
-inline size_t lbc_coef_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64) * 8; }
 
+// k_lbc_coef_apply: the scalar two-loop recursion AND the vector update in ONE launch.
+// Every workgroup (one per 64 weights) repeats the O(m^2) recursion redundantly -- it is the same
+// deterministic code on the same inputs, so all workgroups hold identical coefficients without any
+// inter-workgroup communication -- and then updates its own 64 weights.  Workgroup 0 alone writes
+// the new optimiser state; because the others may still be reading the old one, state, Gram
+// matrices and ro are double buffered (read *_in, write *_out; the host flips per iteration).
+//
 // The recursion runs in *position* space (p = 0 oldest pair ... len-1 newest; lane = position), on
 // three LDS matrices prepared while staging so that a recursion step is exactly
 // {broadcast, fma, fma} with immediate-offset operands and no select:
@@ -433,65 +440,87 @@ inline size_t lbc_coef_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) +
 //   sY[p][j] = y_p.y_j                              backward: y_p.q_0 -= al_j sY[p][j]
 //   sL[p][j] = ro_p (s_j.y_p) for j < p, else 0    forward:  e_p -= cs_j sL[p][j]; e_p is final (= cs_p)
 // (the zeros freeze a lane's value once its own step has passed).  Global reads stay in ring-slot
-// order (one round); the rotation by `head` happens in the LDS write addresses.
-__global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
-    int M1, int m, int max_iter, double lr, double tol_x, double tol_fun, double max_eval,
-    int do_post, int n_theta, LbfgsState* __restrict__ st, LbcExtra* __restrict__ ex,
-    const double* __restrict__ gl, const double* __restrict__ dots, double* __restrict__ SY,
-    double* __restrict__ YY, double* __restrict__ ro, double* __restrict__ cs_out,
-    double* __restrict__ cy_out, int* __restrict__ log_iters, double* __restrict__ log_losses) {
+// order and are issued as one round, including the vector operands of the update; the rotation by
+// `head` happens in the LDS write addresses.
+// d = cg g + sum_j (cy_j y_j + cs_j s_j) is summed over ring *slots* (zero coefficients for slots not
+// in use, ring zeroed at begin), 64 elements x 16 slices per workgroup, fixed order.
+template <typename real>
+__global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
+    int n, int M1, int m, int max_iter, double lr, double tol_x, double tol_fun, double max_eval,
+    int do_post, int n_theta, const LbfgsState* __restrict__ st_in, LbfgsState* __restrict__ st_out,
+    const double* __restrict__ gl, const double* __restrict__ dots,
+    const double* __restrict__ SY_in, const double* __restrict__ YY_in, const double* __restrict__ ro_in,
+    double* __restrict__ SY_out, double* __restrict__ YY_out, double* __restrict__ ro_out,
+    int* __restrict__ log_iters, double* __restrict__ log_losses,
+    const double* __restrict__ Sh, const double* __restrict__ Yh, double* __restrict__ d,
+    double* __restrict__ g_old, double* __restrict__ x, double* __restrict__ theta,
+    real* __restrict__ theta_r, NetDesc nd, float* __restrict__ img) {
   extern __shared__ double lsh[];
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  const bool writer = blockIdx.x == 0;
   const int LD = M1 | 1;
   double* const sU = lsh;
   double* const sL = sU + M1 * LD;
   double* const sY = sL + M1 * LD;
   double* const sT = sY + M1 * LD;                 // 6 x 64 per-slot vectors: say sya yya sg yg ro
+  double* const sC = sT + 6 * 64;                  // cs[64] | cy[64] | {t, cg, apply, will_eval}
+  double* const sP = sC + 192;                     // [16][64] partial sums of the update
   CSTAMP(0);
   // ---- every global read of this kernel, issued as ONE round (a dependent round costs 1.5-2 us)
   const bool in_row = lane < M1;
-  const int done0 = uni(st->done);
-  const int n_iter_prev = uni(st->n_iter), fe_prev = uni(st->func_eval), n_logged = uni(st->n_logged);
-  int head = uni(st->hist_head), len = uni(st->hist_len);
-  double Hdiag = st->Hdiag, f_cur = st->f;
-  const double f_old_prev = st->f_old;
+  const LbfgsState s0 = *st_in;
+  int head = uni(s0.hist_head), len = uni(s0.hist_len);
+  double Hdiag = s0.Hdiag, f_cur = s0.f;
   const double ys = dots[5 * M1 + 0], yy = dots[5 * M1 + 1];
   const double gg = dots[5 * M1 + 2], gabs = dots[5 * M1 + 3], sabs = dots[5 * M1 + 4];
   const double d_say = in_row ? dots[lane] : 0.0, d_sya = in_row ? dots[M1 + lane] : 0.0;
   const double d_yya = in_row ? dots[2 * M1 + lane] : 0.0;
   const double d_sg = in_row ? dots[3 * M1 + lane] : 0.0, d_yg = in_row ? dots[4 * M1 + lane] : 0.0;
-  const double ro_l0 = in_row ? ro[lane] : 0.0;
+  const double ro_l0 = in_row ? ro_in[lane] : 0.0;
   const double f_new = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
   double ra[LBC_ROWS], rb[LBC_ROWS];
 #pragma unroll
   for (int u = 0; u < LBC_ROWS; ++u) {
     const int r = wave + 16 * u;
     const bool ok = r < M1 && in_row;
-    ra[u] = ok ? SY[r * M1 + lane] : 0.0;
-    rb[u] = ok ? YY[r * M1 + lane] : 0.0;
+    ra[u] = ok ? SY_in[r * M1 + lane] : 0.0;
+    rb[u] = ok ? YY_in[r * M1 + lane] : 0.0;
   }
-  if (done0) { if (tid == 0) ex->apply = 0; return; }
+  // vector operands of the update: element i = 64 blockIdx + lane, slice = wave (slots wave + 16u)
+  const int i = blockIdx.x * 64 + lane;
+  const bool iok = i < n;
+  const double gi = (iok && wave == 0) ? gl[i] : 0.0, xi0 = (iok && wave == 0) ? x[i] : 0.0;
+  double yv[4], sv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int sl = wave + 16 * u;
+    const bool ok = iok && sl < M1;
+    yv[u] = ok ? Yh[(size_t)sl * n + i] : 0.0;
+    sv[u] = ok ? Sh[(size_t)sl * n + i] : 0.0;
+  }
+  const int done0 = uni(s0.done);
+  if (done0) { if (writer && tid == 0) *st_out = s0; return; }
   CSTAMP(1);
+  LbfgsState s1 = s0;                              // the state after this iteration (written by `writer`)
   int dn = 0;
   if (do_post) {                                   // custom_lbfgs.py:185-215 for the last evaluation
     f_cur = f_new;
-    if (n_iter_prev == max_iter) dn = 1;
-    else if ((double)(fe_prev + 1) >= max_eval) dn = 3;
+    if (s0.n_iter == max_iter) dn = 1;
+    else if ((double)(s0.func_eval + 1) >= max_eval) dn = 3;
     else if (gabs <= tol_fun) dn = 4;
     else if (sabs <= tol_x) dn = 5;
-    else if (fabs(f_cur - f_old_prev) < tol_x) dn = 6;
-  }
-  if (do_post && tid == 0) {
-    st->f = f_cur; st->func_eval = fe_prev + 1;
-    if (dn) { st->done = dn; ex->apply = 0; ex->will_eval = 0; }
+    else if (fabs(f_cur - s0.f_old) < tol_x) dn = 6;
+    s1.f = f_cur; s1.func_eval = s0.func_eval + 1;
+    if (dn) s1.done = dn;
     else {                                         // :217-224
-      log_iters[n_logged] = n_iter_prev; log_losses[n_logged] = f_cur; st->n_logged = n_logged + 1;
-      if (n_iter_prev == max_iter - 1) st->final_loss = f_cur;
+      if (writer && tid == 0) { log_iters[s0.n_logged] = s0.n_iter; log_losses[s0.n_logged] = f_cur; }
+      s1.n_logged = s0.n_logged + 1;
+      if (s0.n_iter == max_iter - 1) s1.final_loss = f_cur;
     }
   }
-  if (dn) return;
+  if (dn) { if (writer && tid == 0) *st_out = s1; return; }
 
-  const int n_iter = n_iter_prev + 1;
+  const int n_iter = s0.n_iter + 1;
   const bool first = (n_iter == 1);
   int c = head + len; if (c >= M1) c -= M1;
   const bool accept = !first && ys > 1e-10;        // custom_lbfgs.py:102-114
@@ -503,15 +532,14 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
   if (wave == 0) {                                 // per-slot vectors for everybody
     sT[0 * 64 + lane] = d_say; sT[1 * 64 + lane] = d_sya; sT[2 * 64 + lane] = d_yya;
     sT[3 * 64 + lane] = d_sg;  sT[4 * 64 + lane] = d_yg;  sT[5 * 64 + lane] = ro_l;
-    if (accept && lane == c) ro[c] = ro_l;
+    if (writer && in_row) ro_out[lane] = ro_l;
   }
-  lds_barrier();     // LDS-only: must not wait for the global stores above
+  lds_barrier();     // LDS-only: must not wait for global stores
   CSTAMP(2);
   {  // patch the candidate row/column, scale, mask, rotate, stage (branch-free per row)
     int pb = lane - head; if (pb < 0) pb += M1;
     const bool vb = in_row && pb < len;
     const bool lc = accept && lane == c;
-    const int col = in_row ? lane : 0;
     double ro_r[LBC_ROWS], say_r[LBC_ROWS], yya_r[LBC_ROWS];   // LDS reads before LDS writes
 #pragma unroll
     for (int u = 0; u < LBC_ROWS; ++u) {
@@ -530,138 +558,118 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef(
         const double vu = (both && pb > pa) ? ro_r[u] * sy : 0.0;
         const double vy = both ? y2 : 0.0;
         const double vl = (both && pa < pb) ? ro_l * sy : 0.0;
-        if (in_row) { sU[pa * LD + pb] = vu; sY[pa * LD + pb] = vy; sL[pb * LD + pa] = vl; }
-        (void)col;
-      }
-    }
-    if (accept && wave == 0 && in_row) {            // persist the accepted pair's row and column
-      const double sya = (lane == c) ? ys : d_sya, say = (lane == c) ? ys : d_say;
-      const double yya = (lane == c) ? yy : d_yya;
-      SY[c * M1 + lane] = sya; SY[lane * M1 + c] = say;
-      YY[c * M1 + lane] = yya; YY[lane * M1 + c] = yya;
-    }
-  }
-  lds_barrier();     // LDS-only: must not wait for the global stores above
-  if (wave != 0) return;
-  CSTAMP(3);
-
-  // lane = position p
-  int slot = lane + head; if (slot >= M1) slot -= M1;
-  const bool valid = lane < len;
-  const int sidx = in_row ? slot : 0;
-  const double sg_p = valid ? sT[3 * 64 + sidx] : 0.0, yg_p = valid ? sT[4 * 64 + sidx] : 0.0;
-  const double ro_p = valid ? sT[5 * 64 + sidx] : 0.0;
-  const double* __restrict__ rowU = sU + (in_row ? lane : 0) * LD;
-  const double* __restrict__ rowY = sY + (in_row ? lane : 0) * LD;
-  const double* __restrict__ rowL = sL + (in_row ? lane : 0) * LD;
-
-  // Both loops run in chunks of 8 steps: a chunk is straight-line code (its 8-16 LDS operands are
-  // fetched together, ahead of the dependent broadcast->fma chain) and is skipped as a whole when
-  // it lies beyond len.  Steps in [len, M1) inside the last chunk are harmless: their lanes hold
-  // exact zeros and their matrix columns are zero.
-  // backward loop (custom_lbfgs.py:130-133): al_i = ro_i s_i.q_i, q_i = -g - sum_{j>i} al_j y_j
-  double bacc = ro_p * -sg_p, yq0 = -yg_p;
-#pragma unroll
-  for (int c8 = (LBC_MAXSLOTS + 7) / 8 - 1; c8 >= 0; --c8) {
-    if (8 * c8 < len) {
-      double uu[8], yv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = 8 * c8 + k, ic = i < M1 ? i : M1 - 1;
-        uu[k] = rowU[ic]; yv[k] = rowY[ic];
-      }
-#pragma unroll
-      for (int k = 7; k >= 0; --k) {
-        const int i = 8 * c8 + k;
-        const double al_i = (i < M1) ? read_lane(bacc, i) : 0.0;
-        bacc -= al_i * uu[k];
-        yq0 -= al_i * yv[k];
+        if (in_row) {
+          sU[pa * LD + pb] = vu; sY[pa * LD + pb] = vy; sL[pb * LD + pa] = vl;
+          if (writer) { SY_out[r * M1 + lane] = sy; YY_out[r * M1 + lane] = y2; }
+        }
       }
     }
   }
-  const double al = bacc;
-  CSTAMP(4);
-  // forward loop (:136-139): be_i = ro_i y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j), cs_i = al_i - be_i
-  double eacc = al - ro_p * (Hdiag * yq0);
+  lds_barrier();
+  if (wave == 0) {
+    CSTAMP(3);
+    // lane = position p
+    int slot = lane + head; if (slot >= M1) slot -= M1;
+    const bool valid = lane < len;
+    const int sidx = in_row ? slot : 0;
+    const double sg_p = valid ? sT[3 * 64 + sidx] : 0.0, yg_p = valid ? sT[4 * 64 + sidx] : 0.0;
+    const double ro_p = valid ? sT[5 * 64 + sidx] : 0.0;
+    const double* __restrict__ rowU = sU + (in_row ? lane : 0) * LD;
+    const double* __restrict__ rowY = sY + (in_row ? lane : 0) * LD;
+    const double* __restrict__ rowL = sL + (in_row ? lane : 0) * LD;
+    // Both loops run in chunks of 8 steps: a chunk is straight-line code (its 8-16 LDS operands are
+    // fetched together, ahead of the dependent broadcast->fma chain) and is skipped as a whole when
+    // it lies beyond len.  Steps in [len, M1) inside the last chunk are harmless: their lanes hold
+    // exact zeros and their matrix columns are zero.
+    // backward loop (custom_lbfgs.py:130-133): al_i = ro_i s_i.q_i, q_i = -g - sum_{j>i} al_j y_j
+    double bacc = ro_p * -sg_p, yq0 = -yg_p;
 #pragma unroll
-  for (int c8 = 0; c8 < (LBC_MAXSLOTS + 7) / 8; ++c8) {
-    if (8 * c8 < len) {
-      double lv[8];
+    for (int c8 = (LBC_MAXSLOTS + 7) / 8 - 1; c8 >= 0; --c8) {
+      if (8 * c8 < len) {
+        double uu[8], yvv[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = 8 * c8 + k, ic = i < M1 ? i : M1 - 1;
-        lv[k] = rowL[ic];
-      }
+        for (int k = 0; k < 8; ++k) {
+          const int ii = 8 * c8 + k, ic = ii < M1 ? ii : M1 - 1;
+          uu[k] = rowU[ic]; yvv[k] = rowY[ic];
+        }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int i = 8 * c8 + k;
-        const double c_i = (i < M1) ? read_lane(eacc, i) : 0.0;
-        eacc -= c_i * lv[k];
+        for (int k = 7; k >= 0; --k) {
+          const int ii = 8 * c8 + k;
+          const double al_i = (ii < M1) ? read_lane(bacc, ii) : 0.0;
+          bacc -= al_i * uu[k];
+          yq0 -= al_i * yvv[k];
+        }
       }
     }
-  }
-  CSTAMP(5);
-  const double cs = eacc;
-  const double cy = -Hdiag * al;
-  const double cg = -Hdiag;
-  const double gtd = cg * gg + wave_sum(valid ? (cy * yg_p + cs * sg_p) : 0.0);
-  if (in_row) { cs_out[slot] = valid ? cs : 0.0; cy_out[slot] = valid ? cy : 0.0; }
-  if (lane == 0) {
-    st->n_iter = n_iter; st->hist_len = len; st->hist_head = head; st->Hdiag = Hdiag;
-    st->f_old = f_cur;
-    ex->cg = cg; ex->gtd = gtd;
-    if (gtd > -tol_x) {                          // custom_lbfgs.py:154-156
-      st->done = 2; ex->apply = 0; ex->will_eval = 0;
-    } else {
-      double t;
-      if (first) { const double inv = 1.0 / gabs; t = inv < 1.0 ? inv : 1.0; } else t = lr;
-      st->t = t;
-      ex->apply = 1;
-      ex->will_eval = (n_iter != max_iter) ? 1 : 0;
-      if (n_iter == max_iter) st->done = 1;      // :192
-    }
-  }
-  CSTAMP(6);
-}
-
-// d = cg g + sum_j (cy_j y_j + cs_j s_j); g_old = g; x += t d.  Block = 64 elements x 16 slices
-// of the history ring (1024 threads), combined through LDS in a fixed order.  The sum runs over
-// ring *slots*: k_lbc_coef writes zero coefficients for slots not in use (and the ring is zeroed
-// at begin), so nothing here depends on head/len and every global read is issued in one round.
-constexpr int LBA_SLICES = 16;
-template <typename real>
-__global__ __launch_bounds__(64 * LBA_SLICES) void k_lbc_apply(
-    int n, int M1, const LbfgsState* __restrict__ st, const LbcExtra* __restrict__ ex,
-    const double* __restrict__ g, const double* __restrict__ Sh, const double* __restrict__ Yh,
-    const double* __restrict__ cs, const double* __restrict__ cy, double* __restrict__ d,
-    double* __restrict__ g_old, double* __restrict__ x, double* __restrict__ theta,
-    real* __restrict__ theta_r, NetDesc nd, float* __restrict__ img) {
-  __shared__ double sh[LBA_SLICES][64];
-  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + cl;
-  const bool ok = i < n;
-  const int apply = ex->apply, will_eval = ex->will_eval;
-  const double cg = ex->cg, t = st->t;
-  const double gi = (ok && q == 0) ? g[i] : 0.0, xi0 = (ok && q == 0) ? x[i] : 0.0;
-  double p[4];
+    const double al = bacc;
+    CSTAMP(4);
+    // forward loop (:136-139): be_i = ro_i y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j), cs_i = al_i - be_i
+    double eacc = al - ro_p * (Hdiag * yq0);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {                    // slots q, q+16, q+32, q+48 (M1 <= 62)
-    const int sl = q + 16 * u;
-    p[u] = (ok && sl < M1) ? cy[sl] * Yh[(size_t)sl * n + i] + cs[sl] * Sh[(size_t)sl * n + i] : 0.0;
+    for (int c8 = 0; c8 < (LBC_MAXSLOTS + 7) / 8; ++c8) {
+      if (8 * c8 < len) {
+        double lv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = 8 * c8 + k, ic = ii < M1 ? ii : M1 - 1;
+          lv[k] = rowL[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int ii = 8 * c8 + k;
+          const double c_i = (ii < M1) ? read_lane(eacc, ii) : 0.0;
+          eacc -= c_i * lv[k];
+        }
+      }
+    }
+    CSTAMP(5);
+    const double cs = eacc;
+    const double cy = -Hdiag * al;
+    const double cg = -Hdiag;
+    const double gtd = cg * gg + wave_sum(valid ? (cy * yg_p + cs * sg_p) : 0.0);
+    sC[lane] = 0.0; sC[64 + lane] = 0.0;
+    if (in_row) { sC[slot] = valid ? cs : 0.0; sC[64 + slot] = valid ? cy : 0.0; }
+    if (lane == 0) {
+      s1.n_iter = n_iter; s1.hist_len = len; s1.hist_head = head; s1.Hdiag = Hdiag;
+      s1.f_old = f_cur;
+      double apply = 0.0, will_eval = 0.0, t = s0.t;
+      if (gtd > -tol_x) {                          // custom_lbfgs.py:154-156
+        s1.done = 2;
+      } else {
+        if (first) { const double inv = 1.0 / gabs; t = inv < 1.0 ? inv : 1.0; } else t = lr;
+        s1.t = t;
+        apply = 1.0;
+        will_eval = (n_iter != max_iter) ? 1.0 : 0.0;
+        if (n_iter == max_iter) s1.done = 1;       // :192
+      }
+      sC[128] = t; sC[129] = cg; sC[130] = apply; sC[131] = will_eval;
+      if (writer) *st_out = s1;
+    }
+    CSTAMP(6);
   }
-  if (!apply) return;
-  sh[q][cl] = (p[0] + p[1]) + (p[2] + p[3]);
-  __syncthreads();
-  if (q != 0 || !ok) return;
+  lds_barrier();
+  // ---- the update of this workgroup's 64 elements
+  if (sC[130] == 0.0) return;
+  double p = 0.0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int sl = wave + 16 * u;
+    if (sl < M1) p += sC[64 + sl] * yv[u] + sC[sl] * sv[u];
+  }
+  sP[wave * 64 + lane] = p;
+  lds_barrier();
+  if (wave != 0 || !iok) return;
   double hist = 0.0;
 #pragma unroll
-  for (int k = 0; k < LBA_SLICES; ++k) hist += sh[k][cl];
-  const double di = cg * gi + hist;
+  for (int k = 0; k < 16; ++k) hist += sP[k * 64 + lane];
+  const double t = sC[128], di = sC[129] * gi + hist;
   d[i] = di;
   g_old[i] = gi;
   const double xi = xi0 + t * di;
   x[i] = xi;
-  if (will_eval) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
+  if (sC[131] != 0.0) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
 }
+
+inline size_t lbc_coef_apply_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64 + 192 + 16 * 64) * 8; }
 
 }  // namespace pinn
