@@ -94,7 +94,8 @@ __device__ __forceinline__ v4f preact_adjoint4(const v4f s, const v4f ob) {
 
 constexpr int WIMG = 820;
 
-inline size_t fused20m_image_floats(int n_hidden) { return (size_t)(n_hidden - 1) * WIMG; }
+// padded to whole 1-KiB pieces: the image is brought into LDS by asynchronous LDS-DMA
+inline size_t fused20m_image_floats(int n_hidden) { return ((size_t)(n_hidden - 1) * WIMG + 255) / 256 * 256; }
 inline size_t fused20m_lds_bytes(int n_hidden) {
   return fused20m_image_floats(n_hidden) * 4 + (size_t)(4 * FROWS + 4) * 65 * 16;
 }
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
                                                   long long* __restrict__ stamps) {
   constexpr int RS4 = 65;
   constexpr int BUFV = FROWS * RS4;                 // v4f elements per exchange buffer
-  constexpr int NW = (H - 1) * WIMG;                // floats of weight image
+  constexpr int NW = ((H - 1) * WIMG + 255) / 256 * 256;   // floats of weight image (whole DMA pieces)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const wl = reinterpret_cast<float*>(lds_raw);
   v4f* const xb = reinterpret_cast<v4f*>(wl + NW);
@@ -188,9 +189,12 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
   float x = 0.0f, t = 0.0f;
   if (tile < n_tiles) { x = xs[tile * 64 + lane]; t = ts[tile * 64 + lane]; }
 
-  // ---- stage the weight image (16-byte copies) and the two "ones" rows
-  for (int i = tid; i < NW / 4; i += 256)
-    reinterpret_cast<v4f*>(wl)[i] = reinterpret_cast<const v4f*>(img)[i];
+  // ---- weight image -> LDS by asynchronous LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+  // instruction, no registers), in flight while the first tile's input layer is computed; drained
+  // right before the first hidden layer.  Plus the two "ones" rows.
+  for (int c = wave; c < NW / 256; c += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + c * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(wl + c * 256), 16, 0, 0);
   if (wave == 0) {
     xb[0 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
     xb[2 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
@@ -226,8 +230,8 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
   const int fb = min(16 * tj + (lane & 15), FW - 1);          // B column: output feature
   const int kq = (lane >> 4) * 16;                            // this lane group's 16 points
   const int qw = 4 * lane + wave;                             // float index of (point, channel = wave) in a Q row
-  __syncthreads();                                            // weights staged
   STAMP(1);
+  bool image_pending = true;
 
   for (; tile < n_tiles; tile += gridDim.x) {
     const int pt = tile * 64 + lane;
@@ -245,6 +249,10 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       const v4f s{tanh_r5(z), sx * w0x[jj], st * w0t[jj], 0.0f};
       stash[0][jj] = agpr_put4(s);
       xb[feat(jj) * RS4 + lane] = channels4(s);
+    }
+    if (image_pending) {                         // first tile only: this wave's DMA pieces have landed
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      image_pending = false;
     }
     lds_barrier();
 #pragma unroll
