@@ -33,7 +33,10 @@ typedef struct pinn_ctx pinn_ctx;
 enum {
   PINN_PDE_BURGERS = 0,     /* 1d-burgers/inf_cont_burgers.py:65-90   f = u_t + u u_x - nu u_xx            */
   PINN_PDE_BURGERS_IDE = 1, /* 1d-burgers/ide_cont_burgers.py:56-85   f = u_t + l1 u u_x - exp(l2) u_xx    */
-  PINN_PDE_SCHRODINGER = 2  /* 1dcomplex-schrodinger/inf_cont_schrodinger.py:79-129                        */
+  PINN_PDE_SCHRODINGER = 2, /* 1dcomplex-schrodinger/inf_cont_schrodinger.py:79-129                        */
+  /* discrete-time (implicit Runge-Kutta) models: 1 input (x), q or q+1 outputs, see pinn_disc_set_stage */
+  PINN_PDE_BURGERS_DISC = 3,     /* 1d-burgers/inf_disc_burgers.py:57-95   N = U U_x - nu U_xx             */
+  PINN_PDE_BURGERS_DISC_IDE = 4  /* 1d-burgers/ide_disc_burgers.py:81-115  N = l1 U U_x - exp(l2) U_xx     */
 };
 enum { PINN_F32 = 0, PINN_F64 = 1 };
 enum {
@@ -66,7 +69,20 @@ int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_to
 int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, int64_t n_total);
 int pinn_set_boundary(pinn_ctx* c, const double* X_lb, const double* X_ub, int64_t n,
                       int64_t n_total);
-/* get_params (inf_cont_burgers.py:92): p[0] = nu for PINN_PDE_BURGERS */
+/* Discrete-time models (pde_kind 3, 4; layers[0] == 1, lb/ub hold one value each).  A stage set contributes
+ *     sum_{p,j} ( U[p][j] + sum_k N(U)[p][k] M[j][k] - target[p] )^2        (a SUM, inf_disc_burgers.py:92-95)
+ * to the loss, N acting on the first q outputs.  M is [n_out][q] row-major and already carries the step size
+ * (dt * IRK_weights for U_0_model, inf_disc_burgers.py:89; dt * IRK_alpha and -dt * (IRK_beta - IRK_alpha) for
+ * ide_disc_burgers.py:92,108); M == NULL: no IRK term, the set penalises U itself (the walls x_1,
+ * inf_disc_burgers.py:93-95).  target is [n] (broadcast over the outputs like the reference's [n,1] tensor).
+ * set is 0 or 1; its loss is reported in terms[set].  n == 0 removes the set. */
+int pinn_disc_set_stage(pinn_ctx* c, int set, const double* x, const double* target, int64_t n,
+                        const double* M, int q);
+/* U_0_model / U_1_model at arbitrary points with the table of `set` (ide_disc_burgers.py:188-193):
+ * out [n][n_out] = U + N(U) M^T.  pinn_predict returns the plain network outputs U [n][n_out]. */
+int pinn_disc_predict(pinn_ctx* c, int set, const double* x, int64_t n, double* out);
+
+/* get_params (inf_cont_burgers.py:92): p[0] = nu for PINN_PDE_BURGERS and PINN_PDE_BURGERS_DISC */
 int pinn_set_pde_params(pinn_ctx* c, const double* p, int n);
 
 /* get_weights / set_weights (utils/neuralnetwork.py:68-89) */

@@ -62,7 +62,8 @@ def taylor_forward(params, X, lb, ub):
     q = np.zeros_like(h)
     r = np.zeros_like(h)
     p[:, 0] = s[0]
-    q[:, 1] = s[1]
+    if h.shape[1] > 1:          # 1-input nets (discrete-time models): no t channel
+        q[:, 1] = s[1]
     cache = []
     L = len(params)
     for i, (W, b) in enumerate(params):

@@ -1,11 +1,10 @@
-"""Data preparation for the continuous-time Burgers scripts (host side, numpy).
+"""Data preparation for the Burgers scripts (host side, numpy).
 
-Mirrors the two continuous branches of the reference's `prep_data`
-(1d-burgers/burgersutil.py:27-36, 63-75, 99-131): same argument names, same return
-tuples, same order of draws from numpy's global RNG, so that for the same
-`np.random.seed` the training sets are bit-identical (golden hashes in
-tests/golden/burgers_data.json).  The discrete-time (IRK) branches need Butcher tables
-from a submodule the reference does not vendor and are out of scope.
+Mirrors the four branches of the reference's `prep_data` (1d-burgers/burgersutil.py:27-131): same argument
+names, same return tuples, same order of draws from numpy's global RNG, so that for the same `np.random.seed`
+the training sets are bit-identical (golden hashes in tests/golden/burgers_data.json, burgers_disc_*.npz).
+The discrete-time branches need the Butcher tables of a submodule the reference does not vendor; utils/irk.py
+generates them (or reads the original file when `PINNs/Utilities` exists next to the working directory).
 """
 import os
 import sys
@@ -17,17 +16,32 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.append(os.path.join(os.path.dirname(_HERE), "utils"))
 from sampling import lhs  # noqa: E402
 from plotting import newfig, savefig, saveResultDir  # noqa: E402,F401
+from irk import load_butcher  # noqa: E402
+
+# burgersutil.py:17-19 of the reference: where the original Butcher files would live
+utilsPath = os.path.join(".", "PINNs", "Utilities")
 
 
 def prep_data(path, N_u=None, N_f=None, N_n=None, q=None, ub=None, lb=None, noise=0.0,
               idx_t_0=None, idx_t_1=None, N_0=None, N_1=None):
-    if N_n is not None or q is not None or N_0 is not None or N_1 is not None:
-        raise NotImplementedError(
-            "discrete-time (IRK) data preparation is outside this engine's scope")
     mat = scipy.io.loadmat(path)
     t = mat["t"].reshape(-1, 1)
     x = mat["x"].reshape(-1, 1)
     Exact_u = np.real(mat["usol"]).T                  # [T, N]
+
+    if None not in (N_n, q, idx_t_0, idx_t_1) and ub is not None and lb is not None:
+        # discrete-time inference (burgersutil.py:43-61): N_n points of the snapshot idx_t_0, the two walls,
+        # the whole snapshot idx_t_1 as test data, and the q-stage table as [(q+1), q] = [A; b]
+        dt = t[idx_t_1] - t[idx_t_0]
+        pick = np.random.choice(Exact_u.shape[1], N_n, replace=False)
+        x_0 = x[pick, :]
+        u_0 = Exact_u[idx_t_0:idx_t_0 + 1, pick].T
+        u_0 = u_0 + noise * np.std(u_0) * np.random.randn(u_0.shape[0], u_0.shape[1])
+        x_1 = np.vstack((lb, ub))
+        tmp = load_butcher(q, utilsPath)
+        IRK_weights = np.reshape(tmp[0:q ** 2 + q], (q + 1, q))
+        IRK_times = tmp[q ** 2 + q:]
+        return x, t, dt, Exact_u, x_0, u_0, x_1, x, Exact_u[idx_t_1, :], IRK_weights, IRK_times
 
     X, T = np.meshgrid(x, t)
     X_star = np.column_stack((X.ravel(), T.ravel()))
@@ -37,6 +51,23 @@ def prep_data(path, N_u=None, N_f=None, N_n=None, q=None, ub=None, lb=None, nois
     # discarded -- but still drawn -- in the inference branch)
     pick = np.random.choice(X_star.shape[0], N_u, replace=False)
     X_u_train, u_train = X_star[pick, :], u_star[pick, :]
+
+    if N_0 is not None and N_1 is not None:
+        # discrete-time identification (burgersutil.py:78-98): two noisy snapshots, q from the step size
+        E = Exact_u.T
+        pick = np.random.choice(E.shape[0], N_0, replace=False)
+        x_0 = x[pick, :]
+        u_0 = E[pick, idx_t_0][:, None]
+        u_0 = u_0 + noise * np.std(u_0) * np.random.randn(u_0.shape[0], u_0.shape[1])
+        pick = np.random.choice(E.shape[0], N_1, replace=False)
+        x_1 = x[pick, :]
+        u_1 = E[pick, idx_t_1][:, None]
+        u_1 = u_1 + noise * np.std(u_1) * np.random.randn(u_1.shape[0], u_1.shape[1])
+        dt = (t[idx_t_1] - t[idx_t_0]).item()
+        q = int(np.ceil(0.5 * np.log(np.finfo(float).eps) / np.log(dt)))
+        tmp = load_butcher(q, utilsPath)
+        weights = np.reshape(tmp[0:q ** 2 + q], (q + 1, q))
+        return x_0, u_0, x_1, u_1, x, t, dt, q, E, weights[0:-1, :], weights[-1:, :]
 
     lb = X_star.min(axis=0)
     ub = X_star.max(axis=0)

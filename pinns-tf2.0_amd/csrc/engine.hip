@@ -18,6 +18,7 @@
 #include "kernels_wide.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
+#include "kernels_disc.h"
 
 using namespace pinn;
 
@@ -117,6 +118,15 @@ struct pinn_ctx {
   double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
   LbcExtra* lb_ex = nullptr;
 
+  // discrete-time models (pde 3, 4): stage sets as handed over, device copies, scratch
+  struct DiscSet { std::vector<double> x, t, M; int q = 0; bool has_M = false; };
+  DiscSet dset[2];
+  DiscDesc dd{};
+  int* d_ginfo = nullptr;
+  void *d_M[2] = {nullptr, nullptr}, *d_MT[2] = {nullptr, nullptr};
+  void *d_Ast = nullptr, *d_A3 = nullptr, *d_U3 = nullptr, *d_Nn = nullptr, *d_R = nullptr, *d_dAp = nullptr,
+       *d_lossp = nullptr, *d_lamp = nullptr;
+
   // RCCL
   ncclComm_t comm = nullptr;
   int n_ranks = 1, rank = 0;
@@ -132,10 +142,12 @@ struct pinn_ctx {
 };
 
 static size_t real_size(const pinn_ctx* c) { return c->dtype == PINN_F64 ? 8 : 4; }
+static bool is_disc(const pinn_ctx* c) { return c->pde == PINN_PDE_BURGERS_DISC || c->pde == PINN_PDE_BURGERS_DISC_IDE; }
+static bool has_lambdas(int pde) { return pde == PINN_PDE_BURGERS_IDE || pde == PINN_PDE_BURGERS_DISC_IDE; }
 
 // the fused kernel serves width-20 Burgers nets whose staged weights fit the 160 KiB LDS
 static bool fused_ok(const pinn_ctx* c) {
-  if (!fused20_supported(c->nd) || c->pde == PINN_PDE_SCHRODINGER) return false;
+  if (!fused20_supported(c->nd) || c->pde == PINN_PDE_SCHRODINGER || is_disc(c)) return false;
   const size_t lds = c->dtype == PINN_F64 ? fused20_lds_bytes<double>(c->nd.n_hidden)
                                           : fused20_lds_bytes<float>(c->nd.n_hidden);
   return lds <= 160 * 1024;
@@ -143,7 +155,7 @@ static bool fused_ok(const pinn_ctx* c) {
 
 // the register-stash kernel: float32, width 20, instantiated depths, weights + tiles within LDS
 static bool fused_regs_ok(const pinn_ctx* c) {
-  return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER &&
+  return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER && !is_disc(c) &&
          c->nd.n_hidden == 8 && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
 }
 
@@ -249,6 +261,21 @@ struct AdamFuse {          // single-GPU Adam step applied by the reduction kern
   double* loss3;
 };
 
+// deterministic sum of the per-workgroup gradient rows -> c->gl (f64), optionally with the Adam step behind it
+template <typename real>
+static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
+  const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
+  if (af)
+    hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
+                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img);
+  else
+    hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <typename real, int PDE>
 static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   constexpr int JT = sizeof(real) == 4 ? 20 : 10;
@@ -333,20 +360,140 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
   const int n_rows = c->path == 3 ? ((c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu)
                    : c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
-  const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
-  if (af)
-    hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
-                       n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
-                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img);
-  else
-    hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
-                       n_rows, c->R, c->gl);
-  HIPCHK(hipGetLastError());
+  return launch_reduce<real>(c, n_rows, af);
+}
+
+// ------------------------------------------------------------------------------------------
+// discrete-time models: stage-set assembly and the four-launch evaluation (kernels_disc.h)
+// ------------------------------------------------------------------------------------------
+static int disc_layout(pinn_ctx* c, DiscDesc& dd, int n_groups, int q) {
+  dd.n_groups = n_groups; dd.n_pad = 16 * n_groups;
+  dd.ldo = (c->nd.n_out + 63) / 64 * 64; dd.n_chunks = dd.ldo / 64;
+  dd.q = q; dd.wp = (c->nd.width + 15) / 16 * 16;
+  dd.identify = c->pde == PINN_PDE_BURGERS_DISC_IDE ? 1 : 0;
   return 0;
 }
 
+static int disc_upload_tables(pinn_ctx* c, int ldo) {
+  const size_t rs = real_size(c);
+  const int NO = c->nd.n_out;
+  for (int s = 0; s < 2; ++s) {
+    if (c->d_M[s]) { (void)hipFree(c->d_M[s]); c->d_M[s] = nullptr; }
+    if (c->d_MT[s]) { (void)hipFree(c->d_MT[s]); c->d_MT[s] = nullptr; }
+    const pinn_ctx::DiscSet& ds = c->dset[s];
+    if (!ds.has_M || ds.x.empty()) continue;
+    std::vector<double> Mp((size_t)ldo * ldo, 0.0), MTp((size_t)ldo * ldo, 0.0);
+    for (int j = 0; j < NO; ++j)
+      for (int k = 0; k < ds.q; ++k) {
+        const double v = ds.M[(size_t)j * ds.q + k];
+        Mp[(size_t)j * ldo + k] = v;
+        MTp[(size_t)k * ldo + j] = v;
+      }
+    if (dev_alloc(&c->d_M[s], Mp.size() * rs) || dev_alloc(&c->d_MT[s], Mp.size() * rs)) return PINN_EHIP;
+    if (upload_real(c, c->d_M[s], Mp.data(), Mp.size()) || upload_real(c, c->d_MT[s], MTp.data(), MTp.size()))
+      return PINN_EHIP;
+  }
+  return 0;
+}
+
+static int disc_alloc_scratch(pinn_ctx* c, const DiscDesc& dd, void** Ast, void** A3, void** U3, void** Nn,
+                              void** Rb) {
+  const size_t rs = real_size(c), H = c->nd.n_hidden;
+  if (Ast && dev_alloc(Ast, H * 3 * (size_t)dd.n_pad * dd.wp * rs)) return PINN_EHIP;
+  if (A3 && dev_alloc(A3, 3 * (size_t)dd.n_pad * dd.wp * rs)) return PINN_EHIP;
+  if (dev_alloc(U3, 3 * (size_t)dd.n_pad * dd.ldo * rs) || dev_alloc(Nn, (size_t)dd.n_pad * dd.ldo * rs) ||
+      dev_alloc(Rb, (size_t)dd.n_pad * dd.ldo * rs)) return PINN_EHIP;
+  return 0;
+}
+
+static int disc_ensure(pinn_ctx* c) {
+  if (!c->sets_dirty) return 0;
+  const int n0 = (int)c->dset[0].x.size(), n1 = (int)c->dset[1].x.size();
+  REQUIRE(n0 + n1 > 0, "no stage set given (pinn_disc_set_stage)");
+  int q = 0;
+  for (int s = 0; s < 2; ++s)
+    if (!c->dset[s].x.empty() && c->dset[s].has_M) {
+      REQUIRE(q == 0 || q == c->dset[s].q, "the two stage sets use different q (%d vs %d)", q, c->dset[s].q);
+      q = c->dset[s].q;
+    }
+  const int G0 = (n0 + 15) / 16, G1 = (n1 + 15) / 16, G = G0 + G1;
+  DiscDesc dd{};
+  disc_layout(c, dd, G, q);
+  std::vector<double> hx(dd.n_pad, c->lb[0]), ht(dd.n_pad, 0.0);
+  std::vector<int> gi(G);
+  for (int s = 0, g = 0; s < 2; ++s) {
+    const std::vector<double>& x = c->dset[s].x;
+    const int n = (int)x.size();
+    for (int b = 0; b < n; b += 16, ++g) {
+      const int nv = n - b < 16 ? n - b : 16;
+      gi[g] = disc_ginfo(s, nv);
+      for (int i = 0; i < nv; ++i) { hx[16 * g + i] = x[b + i]; ht[16 * g + i] = c->dset[s].t[b + i]; }
+    }
+  }
+  const size_t rs = real_size(c);
+  if (dev_alloc(&c->xs, dd.n_pad * rs) || dev_alloc(&c->tgt, dd.n_pad * rs) ||
+      dev_alloc(&c->d_ginfo, G * sizeof(int))) return PINN_EHIP;
+  c->cap_pts = 0;
+  if (upload_real(c, c->xs, hx.data(), dd.n_pad) || upload_real(c, c->tgt, ht.data(), dd.n_pad)) return PINN_EHIP;
+  HIPCHK(hipMemcpy(c->d_ginfo, gi.data(), G * sizeof(int), hipMemcpyHostToDevice));
+  if (disc_upload_tables(c, dd.ldo)) return PINN_EHIP;
+  if (disc_alloc_scratch(c, dd, &c->d_Ast, &c->d_A3, &c->d_U3, &c->d_Nn, &c->d_R)) return PINN_EHIP;
+  if (dev_alloc(&c->d_dAp, (size_t)dd.n_chunks * 3 * dd.n_pad * dd.wp * rs) ||
+      dev_alloc(&c->d_lossp, (size_t)G * dd.n_chunks * rs) ||
+      dev_alloc(&c->d_lamp, (size_t)G * dd.n_chunks * 2 * rs)) return PINN_EHIP;
+  HIPCHK(hipMemset(c->d_lamp, 0, (size_t)G * dd.n_chunks * 2 * rs));
+  const size_t need_part = (size_t)G * c->R * rs;
+  if (need_part > c->cap_part) { if (dev_alloc(&c->part, need_part)) return PINN_EHIP; c->cap_part = need_part; }
+  HIPCHK(hipMemset(c->part, 0, need_part));
+  c->dd = dd;
+  c->n_rows = G;
+  c->sets_dirty = false;
+  return 0;
+}
+
+template <typename real>
+static int disc_set_lds(size_t fwd, size_t hid) {
+  static size_t cur_f = 0, cur_h = 0;
+  if (fwd > cur_f) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_disc_fwd<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd));
+    cur_f = fwd;
+  }
+  if (hid > cur_h) {
+    HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_hidden<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hid));
+    cur_h = hid;
+  }
+  return 0;
+}
+
+template <typename real>
+static int disc_eval(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
+  const DiscDesc dd = c->dd;
+  const real lbx = (real)c->lb[0], sx = (real)(2.0 / (c->ub[0] - c->lb[0]));
+  const real c1 = real(1), c2 = (real)c->nu;
+  const size_t lds_f = disc_fwd_lds(dd.wp, sizeof(real)), lds_h = disc_hid_lds(dd.wp, sizeof(real));
+  if (int rc = disc_set_lds<real>(lds_f, lds_h)) return rc;
+  const dim3 grid(dd.n_groups, dd.n_chunks), block(256);
+  const real* th = (const real*)c->theta_r;
+  if (ev4) HIPCHK(hipEventRecord(ev4[0], c->stream));
+  hipLaunchKernelGGL((k_disc_fwd<real>), grid, block, lds_f, c->stream, c->nd, dd, th, (const real*)c->xs, lbx, sx,
+                     c1, c2, (real*)c->d_Ast, (real*)c->d_A3, (real*)c->d_U3, (real*)c->d_Nn, 1);
+  hipLaunchKernelGGL((k_disc_irk<real>), grid, block, 0, c->stream, dd, c->nd.n_out, c->d_ginfo,
+                     (const real*)c->d_MT[0], (const real*)c->d_MT[1], (const real*)c->d_Nn,
+                     (const real*)c->d_U3, (const real*)c->tgt, (real*)c->d_R, (real*)c->d_lossp, 0);
+  if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
+  hipLaunchKernelGGL((k_disc_bwd_out<real>), grid, block, 0, c->stream, c->nd, dd, th, c->d_ginfo,
+                     (const real*)c->d_M[0], (const real*)c->d_M[1], (const real*)c->d_R, (const real*)c->d_U3,
+                     (const real*)c->d_A3, c1, c2, (real*)c->part, c->R, (real*)c->d_dAp, (real*)c->d_lamp);
+  hipLaunchKernelGGL((k_disc_bwd_hidden<real>), dim3(dd.n_groups), block, lds_h, c->stream, c->nd, dd, th,
+                     c->d_ginfo, (const real*)c->xs, lbx, sx, (const real*)c->d_Ast, (const real*)c->d_dAp,
+                     (const real*)c->d_lossp, (const real*)c->d_lamp, (real*)c->part, c->R);
+  if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
+  HIPCHK(hipGetLastError());
+  return launch_reduce<real>(c, dd.n_groups, af);
+}
+
 static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
-  int rc = ensure_sets(c);
+  int rc = is_disc(c) ? disc_ensure(c) : ensure_sets(c);
   if (rc) return rc;
   hipEvent_t* ev4 = nullptr;
   if (c->timing && c->ev_used < c->ev_cap_evals && (c->ev_seen++ % c->ev_every) == 0)
@@ -357,12 +504,57 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
     case PINN_PDE_BURGERS_IDE: rc = launch_sweeps<REAL, 1>(c, ev4, af); break;   \
     default: rc = launch_sweeps<REAL, 2>(c, ev4, af); break;                     \
   }
-  if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
+  if (is_disc(c)) rc = c->dtype == PINN_F64 ? disc_eval<double>(c, ev4, af) : disc_eval<float>(c, ev4, af);
+  else if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
 #undef DISPATCH
   if (rc) return rc;
   if (c->comm) NCCLCHK(ncclAllReduce(c->gl, c->gl, (size_t)c->R, ncclDouble, ncclSum, c->comm, c->stream));
   if (ev4) { HIPCHK(hipEventRecord(ev4[3], c->stream)); c->ev_used++; }
   return 0;
+}
+
+// discrete-time models: network outputs (mode 0) or U + N(U) M^T with the table of `set` (mode 1) at n points
+template <typename real>
+static int disc_predict_impl(pinn_ctx* c, int mode, int set, const double* x, int64_t n, double* out) {
+  const int NO = c->nd.n_out;
+  const int G = (int)((n + 15) / 16);
+  DiscDesc dd{};
+  disc_layout(c, dd, G, mode == 1 && c->dset[set].has_M ? c->dset[set].q : 0);
+  std::vector<double> hx(dd.n_pad, c->lb[0]);
+  for (int64_t i = 0; i < n; ++i) hx[i] = x[i];
+  std::vector<int> gi(G, disc_ginfo(set, 16));
+  void *xe = nullptr, *U3 = nullptr, *Nn = nullptr, *Rb = nullptr;
+  int* ge = nullptr;
+  int rc = 0;
+  const size_t rs = sizeof(real);
+  if (dev_alloc(&xe, dd.n_pad * rs) || dev_alloc(&ge, G * sizeof(int)) ||
+      disc_alloc_scratch(c, dd, nullptr, nullptr, &U3, &Nn, &Rb)) rc = PINN_EHIP;
+  if (!rc && upload_real(c, xe, hx.data(), dd.n_pad)) rc = PINN_EHIP;
+  if (!rc && hipMemcpy(ge, gi.data(), G * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = PINN_EHIP;
+  if (!rc) {
+    const real lbx = (real)c->lb[0], sx = (real)(2.0 / (c->ub[0] - c->lb[0]));
+    const size_t lds_f = disc_fwd_lds(dd.wp, rs);
+    rc = disc_set_lds<real>(lds_f, 0);
+    if (!rc) {
+      const dim3 grid(dd.n_groups, dd.n_chunks), block(256);
+      hipLaunchKernelGGL((k_disc_fwd<real>), grid, block, lds_f, c->stream, c->nd, dd, (const real*)c->theta_r,
+                         (const real*)xe, lbx, sx, real(1), (real)c->nu, (real*)nullptr, (real*)nullptr, (real*)U3,
+                         (real*)Nn, 0);
+      if (mode == 1)
+        hipLaunchKernelGGL((k_disc_irk<real>), grid, block, 0, c->stream, dd, NO, ge, (const real*)c->d_MT[0],
+                           (const real*)c->d_MT[1], (const real*)Nn, (const real*)U3, (const real*)nullptr,
+                           (real*)Rb, (real*)nullptr, 1);
+      std::vector<real> ho((size_t)dd.n_pad * dd.ldo);
+      if (hipMemcpyAsync(ho.data(), mode == 1 ? Rb : U3, ho.size() * rs, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess)
+        rc = fail(PINN_EHIP, "discrete-time predict failed: %s", hipGetErrorString(hipGetLastError()));
+      else
+        for (int64_t i = 0; i < n; ++i)
+          for (int j = 0; j < NO; ++j) out[(size_t)i * NO + j] = (double)ho[(size_t)i * dd.ldo + j];
+    }
+  }
+  for (void* ptr : {xe, U3, Nn, Rb, (void*)ge}) if (ptr) (void)hipFree(ptr);
+  return rc;
 }
 
 static int cast_weights(pinn_ctx* c) {
@@ -402,16 +594,19 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
                 const double* ub, int pde_kind, int dtype, int device) {
   REQUIRE(out && layers && lb && ub, "null argument");
   REQUIRE(n_layers >= 3 && n_layers <= MAX_DENSE + 1, "need 3..%d layer sizes, got %d", MAX_DENSE + 1, n_layers);
-  REQUIRE(layers[0] == 2, "input dimension must be 2 (x, t), got %d", layers[0]);
   REQUIRE(dtype == PINN_F32 || dtype == PINN_F64, "dtype must be PINN_F32 or PINN_F64");
-  REQUIRE(pde_kind >= 0 && pde_kind <= 2, "unknown pde kind %d", pde_kind);
+  REQUIRE(pde_kind >= 0 && pde_kind <= 4, "unknown pde kind %d", pde_kind);
+  const bool disc = pde_kind == PINN_PDE_BURGERS_DISC || pde_kind == PINN_PDE_BURGERS_DISC_IDE;
+  if (disc) REQUIRE(layers[0] == 1, "discrete-time models take one input (x), got %d", layers[0]);
+  else REQUIRE(layers[0] == 2, "input dimension must be 2 (x, t), got %d", layers[0]);
   const int W = layers[1], NO = layers[n_layers - 1];
   for (int i = 1; i < n_layers - 1; ++i)
     REQUIRE(layers[i] == W, "all hidden widths must be equal (the reference's sizes_w assumes it, "
                             "utils/neuralnetwork.py:40-45); got %d vs %d", layers[i], W);
   REQUIRE(W >= 1 && W <= MAX_WIDTH, "hidden width %d outside 1..%d", W, MAX_WIDTH);
-  REQUIRE(NO == (pde_kind == PINN_PDE_SCHRODINGER ? 2 : 1), "output size %d does not match the PDE kind", NO);
-  REQUIRE(ub[0] > lb[0] && ub[1] > lb[1], "ub must exceed lb");
+  if (disc) REQUIRE(NO >= 1 && NO <= 65536, "output size %d outside 1..65536", NO);
+  else REQUIRE(NO == (pde_kind == PINN_PDE_SCHRODINGER ? 2 : 1), "output size %d does not match the PDE kind", NO);
+  REQUIRE(ub[0] > lb[0] && (disc || ub[1] > lb[1]), "ub must exceed lb");
   int ndev = 0;
   HIPCHK(hipGetDeviceCount(&ndev));
   REQUIRE(device >= 0 && device < ndev, "device %d not present (%d devices)", device, ndev);
@@ -420,7 +615,8 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   pinn_ctx* c = new pinn_ctx();
   c->device = device; c->dtype = dtype; c->pde = pde_kind; c->n_layers = n_layers;
   for (int i = 0; i < n_layers; ++i) c->layers[i] = layers[i];
-  c->lb[0] = lb[0]; c->lb[1] = lb[1]; c->ub[0] = ub[0]; c->ub[1] = ub[1];
+  c->lb[0] = lb[0]; c->ub[0] = ub[0];
+  if (disc) { c->lb[1] = 0.0; c->ub[1] = 1.0; } else { c->lb[1] = lb[1]; c->ub[1] = ub[1]; }
   c->nu = 0.01 / M_PI;
   NetDesc& nd = c->nd;
   nd.n_hidden = n_layers - 2; nd.width = W; nd.n_out = NO;
@@ -430,7 +626,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
     nd.off_b[d] = off; off += layers[d + 1];
   }
   nd.n_net = off;
-  nd.n_theta = off + (pde_kind == PINN_PDE_BURGERS_IDE ? 2 : 0);
+  nd.n_theta = off + (has_lambdas(pde_kind) ? 2 : 0);
   c->R = nd.n_theta + LOSS_SLOTS;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(PINN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
@@ -477,7 +673,8 @@ int pinn_destroy(pinn_ctx* c) {
                   c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
-                  c->lb_cy, c->lb_ex, c->img};
+                  c->lb_cy, c->lb_ex, c->img, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
+                  c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -492,6 +689,7 @@ int pinn_num_params(pinn_ctx* c, int64_t* n) {
 }
 
 int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_total) {
+  if (c && is_disc(c)) return fail(PINN_EINVAL, "pinn_set_collocation: discrete-time models take stage sets (pinn_disc_set_stage)");
   REQUIRE(c && (X_f || n == 0) && n >= 0 && n_total >= n, "bad collocation arguments");
   c->Xf.assign(X_f, X_f + 2 * n);
   c->nf_total = n_total;
@@ -500,6 +698,7 @@ int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_to
 }
 
 int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, int64_t n_total) {
+  if (c && is_disc(c)) return fail(PINN_EINVAL, "pinn_set_data: discrete-time models take stage sets (pinn_disc_set_stage)");
   REQUIRE(c && ((X_u && u) || n == 0) && n >= 0 && n_total >= n, "bad data arguments");
   c->Xu.assign(X_u, X_u + 2 * n);
   c->U.assign(u, u + (size_t)c->nd.n_out * n);
@@ -509,6 +708,7 @@ int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, in
 }
 
 int pinn_set_boundary(pinn_ctx* c, const double* X_lb, const double* X_ub, int64_t n, int64_t n_total) {
+  if (c && is_disc(c)) return fail(PINN_EINVAL, "pinn_set_boundary: discrete-time models take stage sets (pinn_disc_set_stage)");
   REQUIRE(c && ((X_lb && X_ub) || n == 0) && n >= 0 && n_total >= n, "bad boundary arguments");
   REQUIRE(c->pde == PINN_PDE_SCHRODINGER || n == 0, "boundary pairs are Schrodinger-only");
   c->Xlo.assign(X_lb, X_lb + 2 * n);
@@ -756,6 +956,9 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
   REQUIRE(c && X && out && n >= 0, "bad arguments");
   HIPCHK(hipSetDevice(c->device));
   if (n == 0) return 0;
+  if (is_disc(c))
+    return c->dtype == PINN_F64 ? disc_predict_impl<double>(c, 0, 0, X, n, out)
+                                : disc_predict_impl<float>(c, 0, 0, X, n, out);
   const size_t rs = real_size(c);
   const int NO = c->nd.n_out;
   const size_t W = c->nd.width, H = c->nd.n_hidden;
@@ -792,7 +995,38 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
   return 0;
 }
 
+int pinn_disc_set_stage(pinn_ctx* c, int set, const double* x, const double* target, int64_t n,
+                        const double* M, int q) {
+  REQUIRE(c, "null");
+  REQUIRE(is_disc(c), "pinn_disc_set_stage: the context is not a discrete-time model");
+  REQUIRE(set == 0 || set == 1, "stage set %d outside 0..1", set);
+  REQUIRE(n >= 0 && n <= (1 << 24), "bad point count");
+  REQUIRE(n == 0 || (x && target), "null argument");
+  if (M) REQUIRE(q >= 1 && q <= c->nd.n_out, "q = %d outside 1..n_out (%d)", q, c->nd.n_out);
+  pinn_ctx::DiscSet& ds = c->dset[set];
+  ds.x.assign(x, x + n);
+  ds.t.assign(target, target + n);
+  ds.has_M = M != nullptr && n > 0;
+  ds.q = ds.has_M ? q : 0;
+  if (ds.has_M) ds.M.assign(M, M + (size_t)c->nd.n_out * q); else ds.M.clear();
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_disc_predict(pinn_ctx* c, int set, const double* x, int64_t n, double* out) {
+  REQUIRE(c && x && out && n >= 0, "bad arguments");
+  REQUIRE(is_disc(c), "pinn_disc_predict: the context is not a discrete-time model");
+  REQUIRE(set == 0 || set == 1, "stage set %d outside 0..1", set);
+  HIPCHK(hipSetDevice(c->device));
+  if (n == 0) return 0;
+  int rc = disc_ensure(c);      // uploads the tables
+  if (rc) return rc;
+  return c->dtype == PINN_F64 ? disc_predict_impl<double>(c, 1, set, x, n, out)
+                              : disc_predict_impl<float>(c, 1, set, x, n, out);
+}
+
 int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
+  if (c && is_disc(c)) return fail(PINN_EUNSUPPORTED, "pinn_residual: not defined for discrete-time models");
   REQUIRE(c && f, "null");
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_sets(c);

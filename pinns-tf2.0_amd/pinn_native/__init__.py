@@ -16,10 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_optim.h", "wave.h"]
+SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_wide.h",
+           "kernels_disc.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
-PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2}
+PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2, "burgers_disc": 3, "burgers_disc_ide": 4}
 DTYPES = {"f32": 0, "f64": 1, "float32": 0, "float64": 1}
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
@@ -96,6 +97,10 @@ _SIGNATURES = {
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_disc_set_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_double_p,
+                                           ctypes.c_int64, _c_double_p, ctypes.c_int]),
+    "pinn_disc_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p, ctypes.c_int64,
+                                         _c_double_p]),
     "pinn_comm_unique_id": (ctypes.c_int, [ctypes.c_char_p]),
     "pinn_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int,
                                       ctypes.c_int]),
@@ -181,7 +186,8 @@ class Engine(object):
         self.pde, self.dtype = pde, ("f64" if DTYPES[dtype] else "f32")
         self.n_out = self.layers[-1]
         arr = (ctypes.c_int * len(self.layers))(*self.layers)
-        lb, ub = _f64(lb, (2,)), _f64(ub, (2,))
+        self.n_in = self.layers[0]
+        lb, ub = _f64(lb, (self.n_in,)), _f64(ub, (self.n_in,))
         self._check(self._lib.pinn_create(ctypes.byref(self._h), arr, len(self.layers), _dp(lb),
                                           _dp(ub), PDE_KINDS[pde], DTYPES[dtype], int(device)))
         n = ctypes.c_int64(0)
@@ -250,8 +256,30 @@ class Engine(object):
                                              _dp(grad) if want_grad else None, _dp(terms)))
         return loss.value, grad, terms
 
+    # ---- discrete-time models (pde "burgers_disc", "burgers_disc_ide") -------------------------
+    def disc_set_stage(self, stage, x, target, M=None):
+        """Stage set `stage` (0/1): points x [n], targets [n] (broadcast over the outputs), M [n_out, q] =
+        step-scaled IRK table or None (no IRK term).  See include/pinn_hip.h."""
+        x, target = _f64(x).ravel(), _f64(target).ravel()
+        if x.size != target.size:
+            raise ValueError("x and target must pair up")
+        q = 0
+        if M is not None:
+            M = _f64(M)
+            if M.ndim != 2 or M.shape[0] != self.n_out:
+                raise ValueError("M must be [n_out, q]")
+            q = M.shape[1]
+        self._check(self._lib.pinn_disc_set_stage(self._h, int(stage), _dp(x), _dp(target), x.size,
+                                                  _dp(M) if M is not None else None, q))
+
+    def disc_predict(self, stage, x):
+        x = _f64(x).ravel()
+        out = np.empty((x.size, self.n_out), dtype=np.float64)
+        self._check(self._lib.pinn_disc_predict(self._h, int(stage), _dp(x), x.size, _dp(out)))
+        return out
+
     def predict(self, X):
-        X = _f64(X).reshape(-1, 2)
+        X = _f64(X).reshape(-1, self.n_in)
         out = np.empty((X.shape[0], self.n_out), dtype=np.float64)
         self._check(self._lib.pinn_predict(self._h, _dp(X), X.shape[0], _dp(out)))
         return out

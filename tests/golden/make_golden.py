@@ -23,6 +23,14 @@ What each fixture pins, and from which reference code:
                          (ide_cont_burgers.py, SyntaxError), so this one is produced by a
                          torch nested-autograd restatement of its evident intent, written
                          here (not reference code) and flagged as such in the fixture.
+  burgers_disc_eval*.npz      discrete-time inference: BurgersInformedNN.U_0_model / loss /
+                         get_loss_and_flat_grad / predict of 1d-burgers/inf_disc_burgers.py:57-129 and the
+                         prep_data branch burgersutil.py:43-61, script run unmodified
+  burgers_disc_ide_eval*.npz  discrete-time identification: 1d-burgers/ide_disc_burgers.py:52-196 and
+                         burgersutil.py:78-98, script run unmodified except for three environment
+                         adapters (see gen_burgers_disc): the Butcher table file of the absent PINNs
+                         submodule, np.asscalar (removed from numpy), Logger(frequency=...) (older
+                         Logger signature than utils/logger.py in the same tree)
 """
 import contextlib
 import hashlib
@@ -337,13 +345,118 @@ def gen_burgers_ide_eval():
             tag, float(loss), flat_g[-2], flat_g[-1]))
 
 
+def _install_disc_adapters():
+    """Environment adapters that let the two discrete-time scripts run unmodified:
+    * burgersutil.py:58,91 read PINNs/Utilities/IRK_weights/Butcher_IRK<q>.txt from a git submodule that is not
+      vendored -> np.loadtxt serves the Gauss-Legendre tableau in that file's layout [A | b | c] (the table is
+      third-party *data*; oracle.disc.gauss_legendre_butcher restates its published construction);
+    * burgersutil.py:89 calls np.asscalar (removed in numpy 1.23);
+    * ide_disc_burgers.py:225 calls Logger(frequency=10), a signature utils/logger.py no longer has."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import disc
+    if getattr(np.loadtxt, "_disc_adapter", False):
+        return
+    orig = np.loadtxt
+
+    def loadtxt(path, *a, **k):
+        b = os.path.basename(str(path))
+        if b.startswith("Butcher_IRK"):
+            q = int(b[len("Butcher_IRK"):-4])
+            A, bb, c = disc.gauss_legendre_butcher(q)
+            v = np.concatenate([A.ravel(), bb, c])
+            return v[:, None] if k.get("ndmin") == 2 else v
+        return orig(path, *a, **k)
+    loadtxt._disc_adapter = True
+    np.loadtxt = loadtxt
+    np.asscalar = lambda a: a.item()
+    import logger as ref_logger
+    base = ref_logger.Logger
+
+    class Logger(base):
+        def __init__(self, hp=None, frequency=None):
+            base.__init__(self, {"log_frequency": frequency} if hp is None else hp)
+    ref_logger.Logger = Logger
+
+
+def gen_burgers_disc():
+    import tensorflow as tf
+    _install_disc_adapters()
+    full = {"N_n": 250, "q": 500, "layers": [1, 50, 50, 50, 501], "tf_epochs": 0, "tf_lr": 0.001,
+            "tf_b1": 0.9, "tf_eps": 1e-08, "nt_epochs": 0, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 10}
+    small = dict(full, N_n=64, q=8, layers=[1, 20, 20, 9])
+    for tag, hp in (("", full), ("_small", small)):
+        g, _ = run_reference_script("1d-burgers/inf_disc_burgers.py", hp)
+        pinn = g["pinn"]
+        x_0, u_0, x_1, dt = g["x_0"], g["u_0"], g["x_1"], g["dt"]
+        W_irk, x_star, u_star = g["IRK_weights"], g["x_star"], g["u_star"]
+        w0 = pinn.get_weights().numpy()
+        with contextlib.redirect_stdout(io.StringIO()):
+            xt, ut = pinn.tensor(x_0), pinn.tensor(u_0)
+            # NeuralNetwork.grad (inf_disc_burgers.py:98-101) is the Adam path and records the loss inside the
+            # tape.  The L-BFGS closure (:104-116) computes the loss *outside* its tape: under TensorFlow that
+            # yields None gradients (the script cannot reach L-BFGS), under the torch shim a partial gradient.
+            # Both are recorded; the engine implements the evident intent = the true gradient for both optimisers.
+            loss, grads = pinn.grad(xt, ut)
+            grad = tf.concat([tf.reshape(gg, [-1]) for gg in grads], 0)
+            closure = pinn.get_loss_and_flat_grad(xt, ut)
+            loss_c, grad_c = closure(tf.convert_to_tensor(w0))
+            U0 = pinn.U_0_model(xt).numpy()
+            pred = np.asarray(pinn.predict(x_star))
+            err0 = float(np.linalg.norm(pred - u_star, 2) / np.linalg.norm(u_star, 2))
+            losses, snaps = [], {}
+            for it in range(10):
+                losses.append(float(pinn.tf_optimization_step(xt, ut)))
+                if it + 1 in (1, 10):
+                    snaps["w_after_%d" % (it + 1)] = pinn.get_weights().numpy()
+        np.savez_compressed(
+            os.path.join(HERE, "burgers_disc_eval%s.npz" % tag), hp=json.dumps(hp), w0=w0,
+            loss=float(loss), grad=grad.numpy(), x_0=x_0, u_0=u_0, x_1=x_1, dt=np.asarray(dt, float),
+            irk_dtype=str(W_irk.dtype), irk_shape=np.array(W_irk.shape), irk_sha=sha16(W_irk),
+            irk_corner=np.asarray(W_irk[:3, :3], float), U0_first=U0[:8, :8], U0_sha=sha16(U0),
+            pred_first=pred[:64], err0=err0, adam_losses=np.array(losses),
+            closure_loss=float(loss_c), closure_grad_maxdiff=float(np.abs(grad_c.numpy() - grad.numpy()).max()),
+            **snaps)
+        print("burgers_disc_eval%s: loss=%.17g |g|1=%.10e err0=%.10e adam[9]=%.10e" % (
+            tag, float(loss), float(np.abs(grad.numpy()).sum()), err0, losses[-1]))
+
+    hp_ide = {"N_0": 199, "N_1": 201, "layers": [1, 50, 50, 50, 0], "tf_epochs": 0, "tf_lr": 0.001,
+              "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 0, "nt_lr": 0.8, "nt_ncorr": 50}
+    for tag, hp in (("", hp_ide), ("_small", dict(hp_ide, N_0=48, N_1=40, layers=[1, 20, 20, 0]))):
+        g, _ = run_reference_script("1d-burgers/ide_disc_burgers.py", hp)
+        pinn = g["pinn"]                      # the second ("noisy", noise=0.01) model of the script
+        x_0, u_0, x_1, u_1 = g["x_0"], g["u_0"], g["x_1"], g["u_1"]
+        dt, q, al, be = g["dt"], g["q"], g["IRK_alpha"], g["IRK_beta"]
+        w0 = pinn.get_weights().numpy().copy()
+        w0[-2:] = [0.7, -5.0]                 # off the (0, -6) initial values so every lambda term is live
+        with contextlib.redirect_stdout(io.StringIO()):
+            pinn.set_weights(tf.convert_to_tensor(w0))
+            T = lambda a: tf.convert_to_tensor(a, dtype=pinn.dtype)
+            x0t, u0t, x1t, u1t = T(x_0), T(u_0), T(x_1), T(u_1)
+            loss, grads = pinn.grad(x0t, u0t, x1t, u1t)
+            flat = np.concatenate([np.asarray(gg.numpy()).ravel() for gg in grads])
+            U0p, U1p = pinn.predict(g["x_star"])
+            losses = []
+            for it in range(10):
+                lv, gr = pinn.grad(x0t, u0t, x1t, u1t)
+                pinn.tf_optimizer.apply_gradients(zip(gr, pinn.wrap_training_variables()))
+                losses.append(float(lv))
+            w10 = pinn.get_weights().numpy()
+        np.savez_compressed(
+            os.path.join(HERE, "burgers_disc_ide_eval%s.npz" % tag), hp=json.dumps(hp), w0=w0,
+            loss=float(loss), grad=flat, x_0=x_0, u_0=u_0, x_1=x_1, u_1=u_1, dt=float(dt), q=int(q),
+            irk_sha=sha16(np.concatenate([al, be])), U0_first=U0p.numpy()[:8, :8], U1_first=U1p.numpy()[:8, :8],
+            adam_losses=np.array(losses), w_after_10=w10, layers=np.array(hp["layers"][:-1] + [int(q)]))
+        print("burgers_disc_ide_eval%s: q=%d loss=%.17g dl1=%.6e dl2=%.6e adam[9]=%.10e" % (
+            tag, q, float(loss), flat[-2], flat[-1], losses[-1]))
+
+
 def main():
     os.chdir(REF)
     sys.path.insert(0, SHIMS)
     sys.path.insert(1, os.path.join(REF, "utils"))
     sys.path.insert(2, os.path.join(REF, "1d-burgers"))
     sys.path.insert(3, os.path.join(REF, "1dcomplex-schrodinger"))
-    which = sys.argv[1:] or ["data", "kat", "logger", "burgers", "ide", "schrodinger", "default"]
+    which = sys.argv[1:] or ["data", "kat", "logger", "burgers", "ide", "schrodinger", "default", "disc"]
     if "data" in which:
         gen_burgers_data()
         gen_schrodinger_data()
@@ -359,6 +472,8 @@ def main():
         gen_schrodinger_eval()
     if "default" in which:
         gen_default_run()
+    if "disc" in which:
+        gen_burgers_disc()
 
 
 if __name__ == "__main__":

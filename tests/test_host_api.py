@@ -42,8 +42,6 @@ def test_burgers_identification_branch():
     assert len(r) == g["ide"]["n_returns"] == 11
     assert sha16(r[7]) == g["ide"]["sha"]["X_u"] and sha16(r[8]) == g["ide"]["sha"]["u"]
     assert r[10].tolist() == g["ide"]["lb"] and r[9].tolist() == g["ide"]["ub"]
-    with pytest.raises(NotImplementedError):
-        burgersutil.prep_data(BURGERS_MAT, 10, N_n=5, q=4)
 
 
 def test_schrodinger_prep_data_matches_reference(schrodinger_sets):

@@ -198,3 +198,99 @@ def test_shard_sums_equal_full_batch(burgers_sets):
                                           n_f_total=2048, with_data=(k == 0))
         tot_l, tot_g = tot_l + lo, tot_g + gr
     assert abs(tot_l - full[0]) < 1e-14 and rel(tot_g, full[1]) < 1e-13
+
+
+# ---- discrete-time (IRK) Burgers models ---------------------------------------------------------------------
+def _irk_sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_disc_inference_eval(tag):
+    """oracle/disc.py vs 1d-burgers/inf_disc_burgers.py run unmodified over the shims."""
+    from oracle import disc
+    g = np.load(golden("burgers_disc_eval%s.npz" % tag))
+    hp = json.loads(str(g["hp"]))
+    W, times = disc.irk_tables_like_reference(hp["q"])
+    assert W.dtype == np.float32 and tuple(g["irk_shape"]) == W.shape and _irk_sha(W) == str(g["irk_sha"])
+    sets = disc.inference_sets(g["x_0"], g["u_0"], g["x_1"], g["dt"], W)
+    loss, grad, ex = disc.disc_loss_grad(g["w0"], hp["layers"], [-1.0], [1.0], sets, nu=NU)
+    assert abs(loss - float(g["loss"])) <= 1e-13 * abs(loss)
+    assert rel(grad, g["grad"]) < 1e-12
+    # the closure the reference hands to L-BFGS computes its loss outside the tape (inf_disc_burgers.py:104-116):
+    # same loss value, but not the gradient (recorded in the fixture so the divergence is visible)
+    assert abs(float(g["closure_loss"]) - loss) <= 1e-13 * abs(loss) and float(g["closure_grad_maxdiff"]) > 1e-6
+    params = mlp.unpack(g["w0"], hp["layers"])
+    U0, _, _, _ = disc.stage_prediction(params, g["x_0"], np.array([-1.0]), np.array([1.0]), sets[0][2], 1.0, NU)
+    assert np.max(np.abs(U0[:8, :8] - g["U0_first"])) < 1e-12
+    # Adam trajectory (inf_disc_burgers.py hp: lr 1e-3, eps 1e-8)
+    adam = optim.Adam(hp["tf_lr"], hp["tf_b1"], 0.999, hp["tf_eps"])
+    w = g["w0"].copy()
+    for it in range(10):
+        lv, gr, _ = disc.disc_loss_grad(w, hp["layers"], [-1.0], [1.0], sets, nu=NU)
+        assert abs(lv - g["adam_losses"][it]) <= 1e-11 * abs(lv)
+        w = adam.step(w, gr)
+    assert np.max(np.abs(w - g["w_after_10"])) < 1e-12
+
+
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_disc_identification_eval(tag):
+    """oracle/disc.py vs 1d-burgers/ide_disc_burgers.py (second, noisy model of the script)."""
+    from oracle import disc
+    g = np.load(golden("burgers_disc_ide_eval%s.npz" % tag))
+    q = int(g["q"])
+    assert q == 81                                    # ceil(0.5 log(eps) / log(0.8)), burgersutil.py:90
+    layers = [int(v) for v in g["layers"]]
+    W, _ = disc.irk_tables_like_reference(q)
+    assert _irk_sha(np.concatenate([W[:-1], W[-1:]])) == str(g["irk_sha"])
+    sets = disc.identification_sets(g["x_0"], g["u_0"], g["x_1"], g["u_1"], g["dt"], W[:-1], W[-1:])
+    loss, grad, _ = disc.disc_loss_grad(g["w0"], layers, [-1.0], [1.0], sets, identify=True)
+    assert abs(loss - float(g["loss"])) <= 1e-13 * abs(loss)
+    assert rel(grad, g["grad"]) < 1e-12
+    assert np.max(np.abs(grad[-2:] - g["grad"][-2:])) <= 1e-10 * np.max(np.abs(g["grad"][-2:]))
+    adam = optim.Adam(0.001, 0.9, 0.999, None)
+    w = g["w0"].copy()
+    for it in range(10):
+        lv, gr, _ = disc.disc_loss_grad(w, layers, [-1.0], [1.0], sets, identify=True)
+        assert abs(lv - g["adam_losses"][it]) <= 1e-11 * abs(lv)
+        w = adam.step(w, gr)
+    assert np.max(np.abs(w - g["w_after_10"])) < 1e-12
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 8, 81, 500])
+def test_gauss_legendre_butcher_conditions(q):
+    """The Butcher files of the un-vendored PINNs submodule are restated, not copied: check the construction
+    through the collocation / order / symplecticity conditions and against the product's independent generator."""
+    from oracle import disc
+    import irk
+    A, b, c = disc.gauss_legendre_butcher(q)
+    assert abs(b.sum() - 1.0) < 1e-13 and np.all(b > 0) and np.all(np.diff(c) > 0)
+    for k in range(1, min(q, 10) + 1):
+        assert np.max(np.abs(A @ c ** (k - 1) - c ** k / k)) < 1e-13          # C(q)
+        assert abs(b @ c ** (k - 1) - 1.0 / k) < 1e-13                        # B(q..)
+    assert np.max(np.abs(b[:, None] * A + (b[:, None] * A).T - np.outer(b, b))) < 1e-15   # symplectic
+    if q == 2:
+        assert abs(A[0, 1] - (0.25 - np.sqrt(3.0) / 6.0)) < 1e-15
+    A2, b2, c2 = irk.gauss_legendre_butcher(q)
+    assert np.max(np.abs(A - A2)) < 1e-13 and np.max(np.abs(b - b2)) < 1e-13 and np.max(np.abs(c - c2)) < 1e-13
+
+
+def test_disc_prep_data_matches_reference_draws():
+    """Product burgersutil.prep_data (discrete branches) reproduces the reference's RNG draw order."""
+    import burgersutil
+    g = np.load(golden("burgers_disc_eval.npz"))
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, N_n=250, q=500, lb=np.array([-1.0]), ub=np.array([1.0]), noise=0.0,
+                              idx_t_0=10, idx_t_1=90)
+    assert len(r) == 11 and np.array_equal(r[4], g["x_0"]) and np.array_equal(r[5], g["u_0"])
+    assert np.array_equal(r[6], g["x_1"]) and r[9].shape == (501, 500) and r[9].dtype == np.float32
+    assert abs(float(r[2][0]) - float(g["dt"][0])) == 0.0
+    g = np.load(golden("burgers_disc_ide_eval.npz"))
+    np.random.seed(1234)
+    kw = dict(N_0=199, N_1=201, lb=np.array([-1.0]), ub=np.array([1.0]), idx_t_0=10, idx_t_1=90)
+    burgersutil.prep_data(BURGERS_MAT, noise=0.0, **kw)          # the script's first (clean) call
+    r = burgersutil.prep_data(BURGERS_MAT, noise=0.01, **kw)
+    assert len(r) == 11 and r[7] == 81 and r[9].shape == (81, 81) and r[10].shape == (1, 81)
+    for i, key in enumerate(("x_0", "u_0", "x_1", "u_1")):
+        assert np.array_equal(r[i], g[key])
