@@ -122,3 +122,57 @@ def plot_ide_cont_results(X_star, u_pred, X_u_train, u_train, Exact_u, X, T, x, 
     _field_figure(X_star, u_pred, X, T, x, t, X_u_train, title)
     if save_path is not None and save_hp is not None:
         saveResultDir(save_path, save_hp)
+
+
+def _snapshot_figure(x, Exact_u, t, idx_t_0, idx_t_1, x_0, u_0, x_1, u_1, x_star, u_1_pred, title):
+    """Exact field with the two time slices marked, and the two snapshots (data / prediction) below."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    fig = plt.figure(figsize=(7.5, 6.0))
+    ax = fig.add_subplot(2, 1, 1)
+    im = ax.imshow(Exact_u.T, interpolation="nearest", cmap="rainbow", origin="lower", aspect="auto",
+                   extent=[t.min(), t.max(), x.min(), x.max()])
+    fig.colorbar(im)
+    for idx in (idx_t_0, idx_t_1):
+        ax.axvline(float(t[idx]), color="w", linewidth=1)
+    ax.set_xlabel("t")
+    ax.set_ylabel("x")
+    ax.set_title(title)
+    ax = fig.add_subplot(2, 2, 3)
+    ax.plot(x, Exact_u[idx_t_0, :], "b-", linewidth=2, label="Exact")
+    ax.plot(x_0, u_0, "rx", linewidth=2, label="Data")
+    ax.set_title("t = %.2f" % float(t[idx_t_0]))
+    ax.set_xlabel("x")
+    ax.legend(frameon=False, loc="best")
+    ax = fig.add_subplot(2, 2, 4)
+    ax.plot(x, Exact_u[idx_t_1, :], "b-", linewidth=2, label="Exact")
+    if x_1 is not None and u_1 is not None:
+        ax.plot(x_1, u_1, "rx", linewidth=2, label="Data")
+    if u_1_pred is not None:
+        ax.plot(x_star, u_1_pred, "r--", linewidth=2, label="Prediction")
+    ax.set_title("t = %.2f" % float(t[idx_t_1]))
+    ax.set_xlabel("x")
+    ax.legend(frameon=False, loc="best")
+    fig.tight_layout()
+    return fig
+
+
+def plot_inf_disc_results(x_star, idx_t_0, idx_t_1, x_0, u_0, ub, lb, u_1_pred, Exact_u, x, t,
+                          save_path=None, save_hp=None):
+    """Headless counterpart of burgersutil.py:208-261: exact field, the t_0 data and the predicted t_1 snapshot."""
+    _snapshot_figure(x, Exact_u, t, idx_t_0, idx_t_1, x_0, u_0, None, None, x_star, u_1_pred, "u(t,x)")
+    if save_path is not None and save_hp is not None:
+        saveResultDir(save_path, save_hp)
+
+
+def plot_ide_disc_results(x_star, t_star, idx_t_0, idx_t_1, x_0, u_0, x_1, u_1, ub, lb, U_1_pred, Exact_u,
+                          lambda_1_value, lambda_1_value_noisy, lambda_2_value, lambda_2_value_noisy, x, t,
+                          save_path=None, save_hp=None):
+    """Headless counterpart of burgersutil.py:265-324: both data snapshots and the identified PDE."""
+    title = "u_t + %.5f u u_x - %.7f u_xx = 0   (1%% noise: %.5f, %.7f)" % (
+        lambda_1_value, lambda_2_value, lambda_1_value_noisy, lambda_2_value_noisy)
+    E = Exact_u.T if Exact_u.shape[0] == np.size(x) and Exact_u.shape[1] == np.size(t) else Exact_u
+    _snapshot_figure(x, E, t, idx_t_0, idx_t_1, x_0, u_0, x_1, u_1, x_star, None, title)
+    if save_path is not None and save_hp is not None:
+        saveResultDir(save_path, save_hp)

@@ -17,8 +17,10 @@ _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.append(os.path.join(_root, eqnPath))
 sys.path.append(os.path.join(_root, "utils"))
 from logger import Logger  # noqa: E402
-from neuralnetwork import NeuralNetwork  # noqa: E402
+from neuralnetwork import NeuralNetwork, set_seed  # noqa: E402
 from burgersutil import prep_data, plot_inf_cont_results  # noqa: E402
+
+set_seed(1234)           # the reference's tf.random.set_seed(1234)
 
 if len(sys.argv) > 1:
     with open(sys.argv[1]) as hpFile:

@@ -15,7 +15,9 @@ sys.path.append(os.path.join(_root, eqnPath))
 sys.path.append(os.path.join(_root, "utils"))
 from schrodingerutil import prep_data, plot_inf_cont_results  # noqa: E402
 from logger import Logger  # noqa: E402
-from neuralnetwork import NeuralNetwork  # noqa: E402
+from neuralnetwork import NeuralNetwork, set_seed  # noqa: E402
+
+set_seed(1234)           # the reference's tf.random.set_seed(1234)
 
 np.random.seed(1234)
 

@@ -10,7 +10,7 @@ return shapes (numpy arrays where the reference returns eager tensors).
 
 What changes: there is no TensorFlow, so a subclass cannot spell its PDE with GradientTapes.
 It names one of the engine's residual kinds instead (`pde="burgers" | "burgers_ide" |
-"schrodinger"`) and the engine evaluates forward, u_t/u_x/u_xx, residual, loss and the flat
+"schrodinger" | "burgers_disc" | "burgers_disc_ide"`) and the engine evaluates forward, u_t/u_x/u_xx, residual, loss and the flat
 gradient on the GPU (csrc/).  Extra, optional hp keys: "dtype" ("f32" default | "f64") for
 the kernel arithmetic, "device" (HIP ordinal).  Host interchange stays float64.
 
@@ -24,6 +24,24 @@ import os
 import sys
 sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from pinn_native import Engine  # noqa: E402
+
+
+_INIT_STREAM = {"seed": 1234, "rs": None}
+
+
+def set_seed(seed):
+    """Counterpart of the scripts' `tf.random.set_seed(1234)`: (re)starts the stream the glorot initialisers of
+    all models built afterwards draw from.  As with TensorFlow's global seed, a second model built in the same
+    process continues the stream instead of repeating the first model's weights (the identification scripts
+    build two)."""
+    _INIT_STREAM["seed"] = int(seed)
+    _INIT_STREAM["rs"] = np.random.RandomState(int(seed))
+
+
+def _init_stream():
+    if _INIT_STREAM["rs"] is None:
+        set_seed(_INIT_STREAM["seed"])
+    return _INIT_STREAM["rs"]
 
 
 class _AdamConfig(object):
@@ -64,6 +82,8 @@ def _as_points(X, owner):
     X = np.asarray(X, dtype=np.float64)
     if X.ndim == 1:
         X = X[:, None]
+    if owner.layers[0] == 1:            # discrete-time models: the network input is x alone
+        return X.reshape(-1, 1)
     if X.shape[1] == 1:
         # Schrodinger driver quirk (inf_cont_schrodinger.py:164): x0 of shape [N,1] is handed
         # to a 2-input network.  Default: the evident intent (x0, t=0); hp["compat_x0_broadcast"]
@@ -128,9 +148,10 @@ class NeuralNetwork(object):
     def _initial_weights(self, hp):
         """glorot_normal kernels + zero biases (neuralnetwork.py:31-37): truncated normal within
         two sigma, sigma = sqrt(2/(fan_in+fan_out))/0.87962566103423978, drawn per Dense layer
-        from one RandomState(hp.get("seed", 1234)) -- the engine's canonical initial vector."""
+        from the process-wide stream started by set_seed (default 1234; the first model of a process gets the
+        engine's canonical initial vector), or from a private RandomState(hp["seed"]) when that key is given."""
         from scipy.stats import truncnorm
-        rs = np.random.RandomState(int(hp.get("seed", 1234)))
+        rs = np.random.RandomState(int(hp["seed"])) if "seed" in hp else _init_stream()
         chunks = []
         for fi, fo in zip(self.layers[:-1], self.layers[1:]):
             sigma = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
@@ -175,6 +196,10 @@ class NeuralNetwork(object):
     def get_params(self, numpy=False):
         return []
 
+    def _log_custom(self):
+        """Text appended to a logged progress line (the identification scripts print their lambdas)."""
+        return ""
+
     def get_weights(self, convert_to_tensor=True):
         w = self._engine.get_weights()
         return w if convert_to_tensor else list(w)
@@ -215,7 +240,8 @@ class NeuralNetwork(object):
             stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
             losses = self._engine.adam_run(stop - epoch)
             for k, loss_value in enumerate(losses):
-                self.logger.log_train_epoch(epoch + k, loss_value)
+                last = epoch + k == stop - 1     # the weights on the device are those after this epoch
+                self.logger.log_train_epoch(epoch + k, loss_value, self._log_custom() if last else "")
             epoch = stop
 
     def tf_optimization_step(self, X_u, u):
@@ -238,8 +264,9 @@ class NeuralNetwork(object):
         done = 0
         while not done:
             iters, losses, done = self._engine.lbfgs_run(freq)
-            for it, loss_value in zip(iters, losses):
-                self.logger.log_train_epoch(int(it), loss_value, "", True)
+            for k, (it, loss_value) in enumerate(zip(iters, losses)):
+                custom = self._log_custom() if k == len(iters) - 1 else ""
+                self.logger.log_train_epoch(int(it), loss_value, custom, True)
 
     def nt_optimization_steps(self, loss_and_flat_grad):
         """Host-driven variant with the reference's signature: any closure w -> (loss, grad)."""

@@ -450,6 +450,30 @@ def gen_burgers_disc():
             tag, q, float(loss), flat[-2], flat[-1], losses[-1]))
 
 
+def gen_disc_runs():
+    """stdout of the two discrete-time scripts (unmodified, over the shims).  inf_disc: Adam only -- its L-BFGS
+    closure has no gradient under TensorFlow (see gen_burgers_disc); ide_disc: Adam + L-BFGS, both models."""
+    _install_disc_adapters()
+    hp = {"N_n": 250, "q": 500, "layers": [1, 50, 50, 50, 501], "tf_epochs": 200, "tf_lr": 0.001,
+          "tf_b1": 0.9, "tf_eps": 1e-08, "nt_epochs": 0, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 10}
+    g, out = run_reference_script("1d-burgers/inf_disc_burgers.py", hp)
+    keep = ("tf_epoch", "nt_epoch", "Training finished", "l1", "l2", "noisy")
+    rec = {"hp": hp, "lines": [l for l in out.splitlines() if l.startswith(keep)],
+           "final_error": float(g["error"]())}
+    with open(os.path.join(HERE, "burgers_disc_run.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("disc run: final error %.6e" % rec["final_error"])
+    hp = {"N_0": 199, "N_1": 201, "layers": [1, 50, 50, 50, 0], "tf_epochs": 100, "tf_lr": 0.001, "tf_b1": 0.9,
+          "tf_eps": None, "nt_epochs": 60, "nt_lr": 0.8, "nt_ncorr": 50}
+    g, out = run_reference_script("1d-burgers/ide_disc_burgers.py", hp)
+    rec = {"hp": hp, "lines": [l for l in out.splitlines() if l.startswith(keep)],
+           "lambda_1": float(g["lambda_1_pred"]), "lambda_2": float(g["lambda_2_pred"]),
+           "lambda_1_noisy": float(g["lambda_1_pred_noisy"]), "lambda_2_noisy": float(g["lambda_2_pred_noisy"])}
+    with open(os.path.join(HERE, "burgers_disc_ide_run.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("disc ide run: l1 %.6e l2 %.6e" % (rec["lambda_1"], rec["lambda_2"]))
+
+
 def main():
     os.chdir(REF)
     sys.path.insert(0, SHIMS)
@@ -474,6 +498,8 @@ def main():
         gen_default_run()
     if "disc" in which:
         gen_burgers_disc()
+    if "disc_runs" in which or not sys.argv[1:]:
+        gen_disc_runs()
 
 
 if __name__ == "__main__":

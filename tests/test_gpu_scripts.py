@@ -113,3 +113,58 @@ def test_checkpoint_round_trip_is_bit_exact(tmp_path, monkeypatch):
     assert np.array_equal(a.get_weights(), b.get_weights())
     lb_, _ = b.grad(X_u, u)
     assert la == lb_
+
+
+# ---- discrete-time scripts ----------------------------------------------------------------------------------
+LAMBDAS = re.compile(r"l1 = (\S+)  l2 = (\S+)$")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_inf_disc_burgers_adam_run_matches_reference_log(tmp_path, dtype):
+    """200 Adam epochs of 1d-burgers/inf_disc_burgers.py (q = 500) against the reference script's printed log."""
+    g = json.load(open(golden("burgers_disc_run.json")))
+    hp = dict(g["hp"], dtype=dtype)
+    out = run_script(os.path.join("1d-burgers", "inf_disc_burgers.py"), hp, tmp_path)
+    rows, end = parse(out)
+    ref, ref_end = parse("\n".join(g["lines"]))
+    assert [(r[0], r[1]) for r in rows] == [(r[0], r[1]) for r in ref]
+    tol = 1.5e-4 if dtype == "f64" else 2e-3
+    for (kind, ep, loss), (_, _, loss_ref) in zip(rows, ref):
+        assert abs(loss - loss_ref) <= tol * loss_ref, (kind, ep, loss, loss_ref)
+    assert end is not None and end[0] == ref_end[0]
+    assert abs(end[1] - g["final_error"]) <= (2e-4 if dtype == "f64" else 5e-3), (end, g["final_error"])
+
+
+def test_inf_disc_burgers_lbfgs_converges(tmp_path):
+    """Adam + L-BFGS with the true gradient (the reference's L-BFGS closure has none): the t_1 snapshot is
+    predicted to a few percent after a short schedule."""
+    hp = {"N_n": 250, "q": 100, "layers": [1, 50, 50, 50, 101], "tf_epochs": 100, "tf_lr": 0.001, "tf_b1": 0.9,
+          "tf_eps": 1e-08, "nt_epochs": 400, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 50, "dtype": "f64"}
+    out = run_script(os.path.join("1d-burgers", "inf_disc_burgers.py"), hp, tmp_path)
+    rows, end = parse(out)
+    assert any(r[0] == "nt_epoch" for r in rows)
+    assert rows[-1][2] < 1e-2 * rows[0][2]
+    assert end is not None and end[1] < 0.2, end
+
+
+def test_ide_disc_burgers_run_matches_reference_log(tmp_path):
+    """100 Adam + 60 L-BFGS of 1d-burgers/ide_disc_burgers.py, clean and noisy model, f64: printed losses and
+    lambdas against the reference script's log."""
+    g = json.load(open(golden("burgers_disc_ide_run.json")))
+    hp = dict(g["hp"], dtype="f64")
+    out = run_script(os.path.join("1d-burgers", "ide_disc_burgers.py"), hp, tmp_path)
+    mine = [l for l in out.splitlines() if l.startswith(("tf_epoch", "nt_epoch"))]
+    ref = [l for l in g["lines"] if l.startswith(("tf_epoch", "nt_epoch"))]
+    assert len(mine) == len(ref)
+    for a, b in zip(mine, ref):
+        ma, mb = LINE.match(a), LINE.match(b)
+        assert (ma.group(1), ma.group(2)) == (mb.group(1), mb.group(2))
+        la, lb_ = float(ma.group(3)), float(mb.group(3))
+        nt = ma.group(1) == "nt_epoch"
+        assert abs(la - lb_) <= (2e-2 if nt else 1.5e-4) * lb_, (a, b)
+        xa, xb = LAMBDAS.search(a), LAMBDAS.search(b)
+        assert xa and xb
+        for k in (1, 2):
+            assert abs(float(xa.group(k)) - float(xb.group(k))) <= (2e-2 if nt else 2e-5), (a, b)
+    vals = dict(re.findall(r"^(l1|l2|noisy l1|noisy l2):\s+(\S+)$", out, flags=re.M))
+    assert abs(float(vals["l1"]) - g["lambda_1"]) < 0.05 and abs(float(vals["noisy l1"]) - g["lambda_1_noisy"]) < 0.05
