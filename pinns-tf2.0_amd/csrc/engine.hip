@@ -369,7 +369,7 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
 static int disc_layout(pinn_ctx* c, DiscDesc& dd, int n_groups, int q) {
   dd.n_groups = n_groups; dd.n_pad = 16 * n_groups;
   dd.ldo = (c->nd.n_out + 63) / 64 * 64; dd.n_chunks = dd.ldo / 64;
-  dd.q = q; dd.wp = (c->nd.width + 15) / 16 * 16;
+  dd.q = q; dd.wp = (c->nd.width + 63) / 64 * 64;
   dd.identify = c->pde == PINN_PDE_BURGERS_DISC_IDE ? 1 : 0;
   return 0;
 }
@@ -451,45 +451,51 @@ static int disc_ensure(pinn_ctx* c) {
   return 0;
 }
 
-template <typename real>
-static int disc_set_lds(size_t fwd, size_t hid) {
-  static size_t cur_f = 0, cur_h = 0;
-  if (fwd > cur_f) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_disc_fwd<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fwd));
-    cur_f = fwd;
-  }
-  if (hid > cur_h) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_hidden<real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hid));
-    cur_h = hid;
-  }
+template <typename real, int NT>
+static int disc_set_lds() {
+  static bool done = false;
+  if (done) return 0;
+  HIPCHK(hipFuncSetAttribute((const void*)k_disc_fwd<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)disc_fwd_lds<NT>(sizeof(real))));
+  HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_out<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)disc_out_lds<NT>(sizeof(real))));
+  HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_hidden<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)disc_hid_lds<NT>(sizeof(real))));
+  done = true;
   return 0;
 }
 
-template <typename real>
+template <typename real, int NT>
 static int disc_eval(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const DiscDesc dd = c->dd;
   const real lbx = (real)c->lb[0], sx = (real)(2.0 / (c->ub[0] - c->lb[0]));
   const real c1 = real(1), c2 = (real)c->nu;
-  const size_t lds_f = disc_fwd_lds(dd.wp, sizeof(real)), lds_h = disc_hid_lds(dd.wp, sizeof(real));
-  if (int rc = disc_set_lds<real>(lds_f, lds_h)) return rc;
+  if (int rc = disc_set_lds<real, NT>()) return rc;
   const dim3 grid(dd.n_groups, dd.n_chunks), block(256);
   const real* th = (const real*)c->theta_r;
   if (ev4) HIPCHK(hipEventRecord(ev4[0], c->stream));
-  hipLaunchKernelGGL((k_disc_fwd<real>), grid, block, lds_f, c->stream, c->nd, dd, th, (const real*)c->xs, lbx, sx,
-                     c1, c2, (real*)c->d_Ast, (real*)c->d_A3, (real*)c->d_U3, (real*)c->d_Nn, 1);
+  hipLaunchKernelGGL((k_disc_fwd<real, NT>), grid, block, disc_fwd_lds<NT>(sizeof(real)), c->stream, c->nd, dd, th,
+                     (const real*)c->xs, lbx, sx, c1, c2, (real*)c->d_Ast, (real*)c->d_A3, (real*)c->d_U3,
+                     (real*)c->d_Nn, 1);
   hipLaunchKernelGGL((k_disc_irk<real>), grid, block, 0, c->stream, dd, c->nd.n_out, c->d_ginfo,
                      (const real*)c->d_MT[0], (const real*)c->d_MT[1], (const real*)c->d_Nn,
                      (const real*)c->d_U3, (const real*)c->tgt, (real*)c->d_R, (real*)c->d_lossp, 0);
   if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
-  hipLaunchKernelGGL((k_disc_bwd_out<real>), grid, block, 0, c->stream, c->nd, dd, th, c->d_ginfo,
-                     (const real*)c->d_M[0], (const real*)c->d_M[1], (const real*)c->d_R, (const real*)c->d_U3,
-                     (const real*)c->d_A3, c1, c2, (real*)c->part, c->R, (real*)c->d_dAp, (real*)c->d_lamp);
-  hipLaunchKernelGGL((k_disc_bwd_hidden<real>), dim3(dd.n_groups), block, lds_h, c->stream, c->nd, dd, th,
-                     c->d_ginfo, (const real*)c->xs, lbx, sx, (const real*)c->d_Ast, (const real*)c->d_dAp,
-                     (const real*)c->d_lossp, (const real*)c->d_lamp, (real*)c->part, c->R);
+  hipLaunchKernelGGL((k_disc_bwd_out<real, NT>), grid, block, disc_out_lds<NT>(sizeof(real)), c->stream, c->nd, dd,
+                     th, c->d_ginfo, (const real*)c->d_M[0], (const real*)c->d_M[1], (const real*)c->d_R,
+                     (const real*)c->d_U3, (const real*)c->d_A3, c1, c2, (real*)c->part, c->R, (real*)c->d_dAp,
+                     (real*)c->d_lamp);
+  hipLaunchKernelGGL((k_disc_bwd_hidden<real, NT>), dim3(dd.n_groups), block, disc_hid_lds<NT>(sizeof(real)),
+                     c->stream, c->nd, dd, th, c->d_ginfo, (const real*)c->xs, lbx, sx, (const real*)c->d_Ast,
+                     (const real*)c->d_dAp, (const real*)c->d_lossp, (const real*)c->d_lamp, (real*)c->part, c->R);
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
   HIPCHK(hipGetLastError());
   return launch_reduce<real>(c, dd.n_groups, af);
+}
+
+static int disc_eval_any(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
+  if (c->dtype == PINN_F64) return disc_eval<double, 4>(c, ev4, af);
+  return c->dd.wp == 64 ? disc_eval<float, 4>(c, ev4, af) : disc_eval<float, 8>(c, ev4, af);
 }
 
 static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
@@ -504,7 +510,7 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
     case PINN_PDE_BURGERS_IDE: rc = launch_sweeps<REAL, 1>(c, ev4, af); break;   \
     default: rc = launch_sweeps<REAL, 2>(c, ev4, af); break;                     \
   }
-  if (is_disc(c)) rc = c->dtype == PINN_F64 ? disc_eval<double>(c, ev4, af) : disc_eval<float>(c, ev4, af);
+  if (is_disc(c)) rc = disc_eval_any(c, ev4, af);
   else if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
 #undef DISPATCH
   if (rc) return rc;
@@ -514,7 +520,7 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
 }
 
 // discrete-time models: network outputs (mode 0) or U + N(U) M^T with the table of `set` (mode 1) at n points
-template <typename real>
+template <typename real, int NT>
 static int disc_predict_impl(pinn_ctx* c, int mode, int set, const double* x, int64_t n, double* out) {
   const int NO = c->nd.n_out;
   const int G = (int)((n + 15) / 16);
@@ -533,11 +539,11 @@ static int disc_predict_impl(pinn_ctx* c, int mode, int set, const double* x, in
   if (!rc && hipMemcpy(ge, gi.data(), G * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) rc = PINN_EHIP;
   if (!rc) {
     const real lbx = (real)c->lb[0], sx = (real)(2.0 / (c->ub[0] - c->lb[0]));
-    const size_t lds_f = disc_fwd_lds(dd.wp, rs);
-    rc = disc_set_lds<real>(lds_f, 0);
+    const size_t lds_f = disc_fwd_lds<NT>(rs);
+    rc = disc_set_lds<real, NT>();
     if (!rc) {
       const dim3 grid(dd.n_groups, dd.n_chunks), block(256);
-      hipLaunchKernelGGL((k_disc_fwd<real>), grid, block, lds_f, c->stream, c->nd, dd, (const real*)c->theta_r,
+      hipLaunchKernelGGL((k_disc_fwd<real, NT>), grid, block, lds_f, c->stream, c->nd, dd, (const real*)c->theta_r,
                          (const real*)xe, lbx, sx, real(1), (real)c->nu, (real*)nullptr, (real*)nullptr, (real*)U3,
                          (real*)Nn, 0);
       if (mode == 1)
@@ -555,6 +561,12 @@ static int disc_predict_impl(pinn_ctx* c, int mode, int set, const double* x, in
   }
   for (void* ptr : {xe, U3, Nn, Rb, (void*)ge}) if (ptr) (void)hipFree(ptr);
   return rc;
+}
+
+static int disc_predict_any(pinn_ctx* c, int mode, int set, const double* x, int64_t n, double* out) {
+  if (c->dtype == PINN_F64) return disc_predict_impl<double, 4>(c, mode, set, x, n, out);
+  return c->nd.width <= 64 ? disc_predict_impl<float, 4>(c, mode, set, x, n, out)
+                           : disc_predict_impl<float, 8>(c, mode, set, x, n, out);
 }
 
 static int cast_weights(pinn_ctx* c) {
@@ -604,7 +616,11 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
     REQUIRE(layers[i] == W, "all hidden widths must be equal (the reference's sizes_w assumes it, "
                             "utils/neuralnetwork.py:40-45); got %d vs %d", layers[i], W);
   REQUIRE(W >= 1 && W <= MAX_WIDTH, "hidden width %d outside 1..%d", W, MAX_WIDTH);
-  if (disc) REQUIRE(NO >= 1 && NO <= 65536, "output size %d outside 1..65536", NO);
+  if (disc) {
+    REQUIRE(NO >= 1 && NO <= 65536, "output size %d outside 1..65536", NO);
+    REQUIRE(W <= (dtype == PINN_F64 ? 64 : 128), "discrete-time models: hidden width %d exceeds what the LDS-resident "
+            "kernels hold (64 in float64, 128 in float32)", W);
+  }
   else REQUIRE(NO == (pde_kind == PINN_PDE_SCHRODINGER ? 2 : 1), "output size %d does not match the PDE kind", NO);
   REQUIRE(ub[0] > lb[0] && (disc || ub[1] > lb[1]), "ub must exceed lb");
   int ndev = 0;
@@ -957,8 +973,7 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
   HIPCHK(hipSetDevice(c->device));
   if (n == 0) return 0;
   if (is_disc(c))
-    return c->dtype == PINN_F64 ? disc_predict_impl<double>(c, 0, 0, X, n, out)
-                                : disc_predict_impl<float>(c, 0, 0, X, n, out);
+    return disc_predict_any(c, 0, 0, X, n, out);
   const size_t rs = real_size(c);
   const int NO = c->nd.n_out;
   const size_t W = c->nd.width, H = c->nd.n_hidden;
@@ -1021,8 +1036,7 @@ int pinn_disc_predict(pinn_ctx* c, int set, const double* x, int64_t n, double* 
   if (n == 0) return 0;
   int rc = disc_ensure(c);      // uploads the tables
   if (rc) return rc;
-  return c->dtype == PINN_F64 ? disc_predict_impl<double>(c, 1, set, x, n, out)
-                              : disc_predict_impl<float>(c, 1, set, x, n, out);
+  return disc_predict_any(c, 1, set, x, n, out);
 }
 
 int pinn_residual(pinn_ctx* c, double* f, int64_t n) {

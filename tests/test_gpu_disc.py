@@ -123,3 +123,23 @@ def test_ragged_groups_and_single_set():
         loss, grad, _ = eng.loss_grad()
         lo, go, _ = disc.disc_loss_grad(w, layers, [-1.0], [1.0], [s for s in sets if len(s[0])], nu=NU)
         assert abs(loss - lo) <= 1e-12 * abs(lo) and rel(grad, go) <= 1e-11
+
+
+def test_wide_hidden_layers_f32():
+    """hidden width 100 (> 64): the NT = 8 instantiation, float32 only; float64 refuses it with a message"""
+    import pinn_native
+    from oracle import disc
+    rs = np.random.RandomState(5)
+    q, layers = 12, [1, 100, 100, 13]
+    A, b, c = disc.gauss_legendre_butcher(q)
+    M = 0.2 * np.vstack([A, b[None, :]])
+    x0, t0 = rs.uniform(-1, 1, 40), rs.standard_normal(40)
+    sets = [(x0[:, None], t0[:, None], M), (np.array([[-1.0], [1.0]]), np.zeros((2, 1)), None)]
+    w = 0.3 * rs.standard_normal(sum(a * b + b for a, b in zip(layers[:-1], layers[1:])))
+    eng = make_engine(layers, sets, "f32")
+    eng.set_weights(w)
+    loss, grad, _ = eng.loss_grad()
+    lo, go, _ = disc.disc_loss_grad(w, layers, [-1.0], [1.0], sets, nu=NU)
+    assert abs(loss - lo) <= 2e-5 * abs(lo) and rel(grad, go) <= 2e-4
+    with pytest.raises(pinn_native.PinnNativeError, match="hidden width"):
+        pinn_native.Engine(layers, [-1.0], [1.0], pde="burgers_disc", dtype="f64")
