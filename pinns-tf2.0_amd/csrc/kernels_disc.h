@@ -68,7 +68,7 @@ template <int NT> inline size_t disc_out_lds(size_t rs) {
   return (size_t)(3 * 16 * 68 + 3 * DiscGeo<NT>::CS + DiscGeo<NT>::WP * 68 + 8) * rs;
 }
 template <int NT> inline size_t disc_hid_lds(size_t rs) {
-  return (size_t)(3 * 3 * DiscGeo<NT>::CS + DiscGeo<NT>::WP * DiscGeo<NT>::TLD) * rs;
+  return (size_t)(3 * 3 * DiscGeo<NT>::CS + DiscGeo<NT>::WP * DiscGeo<NT>::TLD + 16) * rs;
 }
 
 // register staging of a [rows <= WP][cols] weight tile: thread t holds elements t, t + 256, ... of the padded
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256) void k_disc_bwd_hidden(NetDesc nd, DiscDesc dd
   real* gz = adj + 3 * CS;                          // adjoint of the pre-activation channels
   real* inp = gz + 3 * CS;                          // the layer's input channels
   real* wt = inp + 3 * CS;                          // [WP][TLD] weights of the layer being reversed
+  real* hs = wt + WP * TLD;                         // [16] normalised inputs of the group's points
   real* __restrict__ row = part + (size_t)G * R_cols;
 
   // in flight from the start: weights of the last hidden layer, its stash and the stash below it
@@ -494,25 +495,39 @@ __global__ __launch_bounds__(256) void k_disc_bwd_hidden(NetDesc nd, DiscDesc dd
   load_stash(sc, H - 1);
   if (H > 1) load_stash(sp, H - 2);
 
-  {  // adjoint of the last hidden layer = sum of the chunk partials, 4 loads in flight per element
+  {  // adjoint of the last hidden layer = sum of the chunk partials (fixed order), 4 chunks x all of this
+     // thread's elements in flight per round
     const int nch = dd.n_chunks;
+    const size_t cstride = (size_t)3 * n_pad * WP;
+    real s[3][EPT];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) s[c][e] = 0;
+    for (int c0 = 0; c0 < nch; c0 += 4) {
+      real v[3][EPT][4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const int i = tid + 256 * e;
+          const real* src = dAp + ((size_t)c * n_pad + 16 * G + i / WP) * WP + i % WP + (size_t)c0 * cstride;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[c][e][u] = c0 + u < nch ? src[(size_t)u * cstride] : real(0);
+        }
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) s[c][e] += (v[c][e][0] + v[c][e][1]) + (v[c][e][2] + v[c][e][3]);
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const int i = tid + 256 * e, p = i / WP, k = i % WP;
-        const real* src = dAp + ((size_t)c * n_pad + 16 * G + p) * WP + k;
-        const size_t cstride = (size_t)3 * n_pad * WP;
-        real s = 0;
-        for (int c0 = 0; c0 < nch; c0 += 4) {
-          const real v0 = src[(size_t)c0 * cstride];
-          const real v1 = c0 + 1 < nch ? src[(size_t)(c0 + 1) * cstride] : real(0);
-          const real v2 = c0 + 2 < nch ? src[(size_t)(c0 + 2) * cstride] : real(0);
-          const real v3 = c0 + 3 < nch ? src[(size_t)(c0 + 3) * cstride] : real(0);
-          s += (v0 + v1) + (v2 + v3);
-        }
-        adj[c * CS + p * LD + k] = s;
+        const int i = tid + 256 * e;
+        adj[c * CS + (i / WP) * LD + i % WP] = s[c][e];
       }
+    if (tid < 16) hs[tid] = sx * (xs[16 * G + tid] - lbx) - real(1);
   }
   if (tid == 0) {   // loss slot of this group's stage set; identification parameters
     real s = 0;
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(256) void k_disc_bwd_hidden(NetDesc nd, DiscDesc dd
       for (int p = 0; p < 16; ++p) {
         const real zb = gz[0 * CS + p * LD + tid];
         sb += zb;
-        if (l == 0) sw += (sx * (xs[16 * G + p] - lbx) - real(1)) * zb + sx * gz[1 * CS + p * LD + tid];
+        if (l == 0) sw += hs[p] * zb + sx * gz[1 * CS + p * LD + tid];
       }
       row[nd.off_b[l] + tid] = sb;
       if (l == 0) row[nd.off_w[0] + tid] = sw;
