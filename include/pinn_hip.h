@@ -67,6 +67,14 @@ int pinn_num_params(pinn_ctx* c, int64_t* n);       /* incl. lambda_1, lambda_2 
  *   boundary:    X_lb, X_ub              (inf_cont_schrodinger.py:50-53), Schrodinger only. */
 int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_total);
 int pinn_set_data(pinn_ctx* c, const double* X_u, const double* u, int64_t n, int64_t n_total);
+/* Collocation points drawn on the device instead of handed over: points [first, first + count) of an
+ * n_design-point Latin hypercube over [lb, ub] -- the role of `lb + (ub - lb) * lhs(2, N_f)`
+ * (1d-burgers/burgersutil.py:122), same kind of design, counter-based stream (csrc/kernels_sampling.h), so ranks
+ * can build disjoint shards of one design and a re-draw with a new seed is a single launch (no reallocation when
+ * count is unchanged).  The mean() denominator becomes n_design.  pinn_get_collocation reads the current set
+ * back, [n][2] float64 (also valid after pinn_set_collocation). */
+int pinn_lhs_collocation(pinn_ctx* c, int64_t n_design, int64_t first, int64_t count, uint64_t seed);
+int pinn_get_collocation(pinn_ctx* c, double* X, int64_t n);
 int pinn_set_boundary(pinn_ctx* c, const double* X_lb, const double* X_ub, int64_t n,
                       int64_t n_total);
 /* Discrete-time models (pde_kind 3, 4; layers[0] == 1, lb/ub hold one value each).  A stage set contributes

@@ -19,6 +19,7 @@
 #include "kernels_generic.h"
 #include "kernels_optim.h"
 #include "kernels_disc.h"
+#include "kernels_sampling.h"
 
 using namespace pinn;
 
@@ -118,6 +119,9 @@ struct pinn_ctx {
   double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
   LbcExtra* lb_ex = nullptr;
 
+  // collocation set generated on the device (pinn_lhs_collocation) instead of handed over
+  struct { bool on = false; int64_t n_design = 0, first = 0, count = 0; uint64_t seed = 0; } lhs;
+
   // discrete-time models (pde 3, 4): stage sets as handed over, device copies, scratch
   struct DiscSet { std::vector<double> x, t, M; int q = 0; bool has_M = false; };
   DiscSet dset[2];
@@ -186,13 +190,33 @@ static int upload_real(pinn_ctx* c, void* dst, const double* src, size_t n) {
   return 0;
 }
 
+// device-side Latin hypercube: (re)writes the collocation slots of xs/ts in place (kernels_sampling.h)
+static int lhs_fill(pinn_ctx* c) {
+  const int64_t cnt = c->lhs.count;
+  if (cnt <= 0) return 0;
+  const size_t off = (size_t)(2 * c->sd.n_b + c->sd.n_u);
+  const uint64_t n = (uint64_t)c->lhs.n_design;
+  const uint32_t lo = (uint32_t)c->lhs.seed, hi = (uint32_t)(c->lhs.seed >> 32);
+  const dim3 grid((unsigned)((cnt + 255) / 256)), block(256);
+  if (c->dtype == PINN_F64)
+    hipLaunchKernelGGL((k_lhs_fill<double>), grid, block, 0, c->stream, (double*)c->xs + off, (double*)c->ts + off, cnt,
+                       (uint64_t)c->lhs.first, n, lhs_half_bits(n), lo, hi, c->lb[0], c->lb[1], c->ub[0] - c->lb[0],
+                       c->ub[1] - c->lb[1]);
+  else
+    hipLaunchKernelGGL((k_lhs_fill<float>), grid, block, 0, c->stream, (float*)c->xs + off, (float*)c->ts + off, cnt,
+                       (uint64_t)c->lhs.first, n, lhs_half_bits(n), lo, hi, c->lb[0], c->lb[1], c->ub[0] - c->lb[0],
+                       c->ub[1] - c->lb[1]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // training-set assembly: [boundary-lo | boundary-hi | data | collocation | pad]
 // ------------------------------------------------------------------------------------------
 static int ensure_sets(pinn_ctx* c) {
   if (!c->sets_dirty) return 0;
   const int n_b = (int)(c->Xlo.size() / 2), n_u = (int)(c->Xu.size() / 2),
-            n_f = (int)(c->Xf.size() / 2);
+            n_f = c->lhs.on ? (int)c->lhs.count : (int)(c->Xf.size() / 2);
   const int NO = c->nd.n_out;
   if (c->pde == PINN_PDE_BURGERS_IDE)
     REQUIRE(n_f == 0, "identification evaluates the residual at the data points; no collocation set");
@@ -216,8 +240,9 @@ static int ensure_sets(pinn_ctx* c) {
     hx[g] = c->Xu[2 * i]; ht[g] = c->Xu[2 * i + 1];
     for (int o = 0; o < NO; ++o) htg[(size_t)o * n_pad + g] = c->U[(size_t)i * NO + o];
   }
-  for (int i = 0; i < n_f; ++i, ++g) { hx[g] = c->Xf[2 * i]; ht[g] = c->Xf[2 * i + 1]; }
-  for (; g < n_pad; ++g) { hx[g] = c->lb[0]; ht[g] = c->lb[1]; }   // inert padding (zero seeds)
+  if (!c->lhs.on)
+    for (int i = 0; i < n_f; ++i, ++g) { hx[g] = c->Xf[2 * i]; ht[g] = c->Xf[2 * i + 1]; }
+  for (; g < n_pad; ++g) { hx[g] = c->lb[0]; ht[g] = c->lb[1]; }   // inert padding (zero seeds); LHS slots filled below
 
   const size_t rs = real_size(c);
   if ((size_t)n_pad > c->cap_pts) {
@@ -230,6 +255,7 @@ static int ensure_sets(pinn_ctx* c) {
   if (upload_real(c, c->xs, hx.data(), n_pad)) return PINN_EHIP;
   if (upload_real(c, c->ts, ht.data(), n_pad)) return PINN_EHIP;
   if (upload_real(c, c->tgt, htg.data(), (size_t)NO * n_pad)) return PINN_EHIP;
+  if (c->lhs.on) { if (int rc = lhs_fill(c)) return rc; }
 
   c->chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
   c->n_rows = c->chunk / 64;
@@ -709,7 +735,45 @@ int pinn_set_collocation(pinn_ctx* c, const double* X_f, int64_t n, int64_t n_to
   REQUIRE(c && (X_f || n == 0) && n >= 0 && n_total >= n, "bad collocation arguments");
   c->Xf.assign(X_f, X_f + 2 * n);
   c->nf_total = n_total;
+  c->lhs.on = false;
   c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_lhs_collocation(pinn_ctx* c, int64_t n_design, int64_t first, int64_t count, uint64_t seed) {
+  REQUIRE(c, "null");
+  REQUIRE(!is_disc(c) && c->pde != PINN_PDE_BURGERS_IDE, "pinn_lhs_collocation: this model has no collocation set");
+  REQUIRE(n_design >= 1 && first >= 0 && count >= 0 && first + count <= n_design && count <= (1 << 30),
+          "bad design geometry (n_design %lld, first %lld, count %lld)", (long long)n_design, (long long)first,
+          (long long)count);
+  HIPCHK(hipSetDevice(c->device));
+  const bool same_shape = c->lhs.on && !c->sets_dirty && c->lhs.count == count;
+  c->lhs.on = true; c->lhs.n_design = n_design; c->lhs.first = first; c->lhs.count = count; c->lhs.seed = seed;
+  c->Xf.clear();
+  c->nf_total = n_design;
+  c->sd.inv_nf = 1.0 / (double)n_design;
+  if (same_shape) return lhs_fill(c);            // re-draw in place: one launch, nothing reallocated
+  c->sets_dirty = true;
+  return 0;
+}
+
+int pinn_get_collocation(pinn_ctx* c, double* X, int64_t n) {
+  REQUIRE(c && (X || n == 0), "null");
+  REQUIRE(!is_disc(c), "pinn_get_collocation: discrete-time models have stage sets");
+  HIPCHK(hipSetDevice(c->device));
+  int rc = ensure_sets(c);
+  if (rc) return rc;
+  REQUIRE(n == c->sd.n_f, "buffer holds %lld points, the collocation set has %d", (long long)n, c->sd.n_f);
+  if (n == 0) return 0;
+  const size_t off = (size_t)(2 * c->sd.n_b + c->sd.n_u), rs = real_size(c);
+  std::vector<char> hx((size_t)n * rs), ht((size_t)n * rs);
+  HIPCHK(hipMemcpyAsync(hx.data(), (const char*)c->xs + off * rs, hx.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(ht.data(), (const char*)c->ts + off * rs, ht.size(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < n; ++i) {
+    X[2 * i] = c->dtype == PINN_F64 ? ((const double*)hx.data())[i] : (double)((const float*)hx.data())[i];
+    X[2 * i + 1] = c->dtype == PINN_F64 ? ((const double*)ht.data())[i] : (double)((const float*)ht.data())[i];
+  }
   return 0;
 }
 

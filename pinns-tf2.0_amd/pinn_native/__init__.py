@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
 SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_wide.h",
-           "kernels_disc.h", "kernels_optim.h", "wave.h"]
+           "kernels_disc.h", "kernels_sampling.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
 PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2, "burgers_disc": 3, "burgers_disc_ide": 4}
@@ -97,6 +97,9 @@ _SIGNATURES = {
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_lhs_collocation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_uint64]),
+    "pinn_get_collocation": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_disc_set_stage": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p, _c_double_p,
                                            ctypes.c_int64, _c_double_p, ctypes.c_int]),
     "pinn_disc_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p, ctypes.c_int64,
@@ -217,6 +220,17 @@ class Engine(object):
         self.n_f = X_f.shape[0]
         self._check(self._lib.pinn_set_collocation(self._h, _dp(X_f), self.n_f,
                                                    self.n_f if n_total is None else int(n_total)))
+
+    def lhs_collocation(self, n_design, seed, first=0, count=None):
+        """Draw collocation points [first, first+count) of an n_design-point Latin hypercube on the device."""
+        count = int(n_design) - int(first) if count is None else int(count)
+        self._check(self._lib.pinn_lhs_collocation(self._h, int(n_design), int(first), count, int(seed)))
+        self.n_f = count
+
+    def get_collocation(self):
+        X = np.empty((self.n_f, 2), dtype=np.float64)
+        self._check(self._lib.pinn_get_collocation(self._h, _dp(X), self.n_f))
+        return X
 
     def set_data(self, X_u, u, n_total=None):
         X_u = _f64(X_u).reshape(-1, 2)

@@ -136,6 +136,10 @@ class NeuralNetwork(object):
                                self.tf_optimizer.beta_2, self.tf_optimizer.epsilon)
         self._bound = None
         self.logger = logger
+        # optional: re-draw the collocation set on the device every k Adam epochs (not in the reference, which
+        # samples once on the host).  Seeds are resample_seed + epoch.
+        self._resample_every = int(hp.get("resample_every", 0))
+        self._resample_seed = int(hp.get("resample_seed", 1234))
 
     # ---- initialisation ------------------------------------------------------------------------
     def _n_net(self):
@@ -235,9 +239,14 @@ class NeuralNetwork(object):
         self._bind(X_u, u)
         freq = max(int(self.logger.frequency), 1)
         epoch = 0
+        k = self._resample_every if self._engine.n_f > 0 else 0
         while epoch < self.tf_epochs:
+            if k and epoch > 0 and epoch % k == 0:
+                self._engine.lhs_collocation(self._engine.n_f, self._resample_seed + epoch)
             # run up to and including the next epoch that is logged, then sync once
             stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
+            if k:
+                stop = min(stop, (epoch // k + 1) * k)
             losses = self._engine.adam_run(stop - epoch)
             for k, loss_value in enumerate(losses):
                 last = epoch + k == stop - 1     # the weights on the device are those after this epoch

@@ -294,3 +294,24 @@ def test_disc_prep_data_matches_reference_draws():
     assert len(r) == 11 and r[7] == 81 and r[9].shape == (81, 81) and r[10].shape == (1, 81)
     for i, key in enumerate(("x_0", "u_0", "x_1", "u_1")):
         assert np.array_equal(r[i], g[key])
+
+
+# ---- device Latin-hypercube generator: the numpy restatement the GPU test compares against ------------------
+def test_lhs_restatement_philox_known_answers_and_bijection():
+    from oracle import lhs
+    z = np.array([0], dtype=np.uint64)
+    f = np.array([0xFFFFFFFF], dtype=np.uint64)
+    # Random123 known-answer vectors for philox4x32-10
+    assert [int(v[0]) for v in lhs.philox4x32_10(z, z, z, z, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(v[0]) for v in lhs.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    for n in (1, 2, 3, 17, 1000, 4097):
+        i = np.arange(n, dtype=np.uint64)
+        p = lhs.permute(i, n, 0x9ABCDEF0, 0x12345678)
+        assert np.array_equal(np.sort(p), i)
+    X, _ = lhs.lhs_points(2048, 99, [-1.0, 0.0], [1.0, 0.99])
+    assert X[:, 0].min() >= -1.0 and X[:, 0].max() < 1.0 and X[:, 1].min() >= 0.0 and X[:, 1].max() < 0.99
+    for d, (lo, hi) in enumerate(((-1.0, 1.0), (0.0, 0.99))):
+        strata = np.floor((X[:, d] - lo) / (hi - lo) * 2048).astype(int)
+        assert np.array_equal(np.sort(strata), np.arange(2048))
+    # a different seed is a different design
+    assert not np.array_equal(X, lhs.lhs_points(2048, 100, [-1.0, 0.0], [1.0, 0.99])[0])
