@@ -1,0 +1,76 @@
+"""GPU: randomized shape sweep of the continuous models through the C ABI against the oracle -- widths 1..128,
+2..12 dense layers, ragged point counts, all three residual kinds, f64 (1e-10) and f32 (5e-5): every kernel family
+the engine can choose for a shape (generic, HBM-stash width-20, register-stash 8x20, wide MFMA) is hit by some
+case, and for shapes with several eligible families all of them are compared."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NU = 0.01 / np.pi
+LB, UB = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
+
+
+def cases():
+    rs = np.random.RandomState(2026)
+    out = []
+    fixed = [("burgers", 20, 8), ("burgers_ide", 20, 8), ("burgers", 20, 3), ("schrodinger", 100, 4),
+             ("burgers", 1, 1), ("burgers", 128, 2), ("schrodinger", 24, 3), ("burgers_ide", 7, 11)]
+    for pde, W, H in fixed:
+        out.append((pde, W, H, int(rs.randint(1, 700)), int(rs.randint(1, 90)), int(rs.randint(0, 2 ** 31))))
+    for _ in range(10):
+        pde = ["burgers", "burgers_ide", "schrodinger"][rs.randint(3)]
+        out.append((pde, int(rs.randint(1, 129)), int(rs.randint(1, 7)), int(rs.randint(1, 1500)),
+                    int(rs.randint(1, 120)), int(rs.randint(0, 2 ** 31))))
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("pde_kind,W,H,n_f,n_u,seed", cases())
+def test_random_shapes_against_oracle(pde_kind, W, H, n_f, n_u, seed, dtype):
+    import pinn_native
+    from oracle import pde
+    rs = np.random.RandomState(seed)
+    n_out = 2 if pde_kind == "schrodinger" else 1
+    layers = [2] + [W] * H + [n_out]
+    P = sum(a * b + b for a, b in zip(layers[:-1], layers[1:]))
+    scale = 0.9 / np.sqrt(max(W, 2))
+    w = scale * rs.standard_normal(P)
+    pts = lambda n: np.column_stack([rs.uniform(LB[0], UB[0], n), rs.uniform(LB[1], UB[1], n)])
+    X_f, X_u = pts(n_f), pts(n_u)
+    u = rs.standard_normal((n_u, n_out))
+    eng = pinn_native.Engine(layers, LB, UB, pde=pde_kind, dtype=dtype)
+    if pde_kind == "burgers":
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(NU)
+        ref = pde.burgers_loss_grad(w, layers, LB, UB, X_f, X_u, u, NU)
+    elif pde_kind == "burgers_ide":
+        w = np.concatenate([w, [0.6, -4.5]])
+        eng.set_data(X_u, u)
+        ref = pde.burgers_ide_loss_grad(w, layers, LB, UB, X_u, u)
+    else:
+        n_b = int(rs.randint(1, 40))
+        tb = rs.uniform(LB[1], UB[1], (n_b, 1))
+        X_lb, X_ub = np.hstack([0 * tb + LB[0], tb]), np.hstack([0 * tb + UB[0], tb])
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_boundary(X_lb, X_ub)
+        ref = pde.schrodinger_loss_grad(w, layers, LB, UB, X_f, X_lb, X_ub, X_u, u)
+    tl, tg = (1e-11, 1e-10) if dtype == "f64" else (2e-5, 5e-5)
+    default = eng.kernel_path()
+    tried = 0
+    for path in (default, 0, 1, 2, 3):
+        if tried and path == default:
+            continue
+        try:
+            eng.set_kernel_path(path)
+        except pinn_native.PinnNativeError:
+            continue
+        tried += 1
+        eng.set_weights(w)
+        loss, grad, _ = eng.loss_grad()
+        assert abs(loss - ref[0]) <= tl * max(abs(ref[0]), 1e-3), (path, loss, ref[0])
+        assert rel(grad, ref[1]) <= tg, (path, rel(grad, ref[1]))
+    assert tried >= 1
+    eng.close()
