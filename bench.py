@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--kernel-path", type=int, default=-1, help="-1 engine default, 0 generic, 1 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-error", action="store_true")
+    ap.add_argument("--no-f64-leg", action="store_true", help="skip the float64 (reference arithmetic) timing leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -197,6 +198,32 @@ def main():
         u_pred = eng.predict(X_star)
         final_err = float(np.linalg.norm(u_star - u_pred, 2) / np.linalg.norm(u_star, 2))
 
+    # ---- float64 leg (untimed for `value`; N=1 only): the same K iterations in the reference's arithmetic ----
+    f64_leg = None
+    if world == 1 and args.dtype == "f32" and not args.no_f64_leg:
+        e64 = make_engine("f64", local_rank, X_f, X_u, u, lb, ub, world, rank, n_f_total, 100)
+        e64.set_weights(w0)
+        e64.adam_init(0.03, 0.9, 0.999, 1e-7)
+        e64.adam_run(max(args.warmup // 3, 1), want_losses=False)
+        e64.lbfgs_begin(max(k_lbfgs, 4), 0.8, 50, float(np.finfo(float).eps))
+        e64.lbfgs_run(max(args.warmup - args.warmup // 3, 2))
+        e64.set_weights(w0)
+        e64.adam_init(0.03, 0.9, 0.999, 1e-7)
+        e64.sync()
+        t1 = time.perf_counter()
+        if k_adam:
+            e64.adam_run(k_adam, want_losses=False)
+        if k_lbfgs:
+            e64.lbfgs_begin(k_lbfgs, 0.8, 50, float(np.finfo(float).eps))
+            d3 = 0
+            while not d3:
+                _, _, d3 = e64.lbfgs_run(k_lbfgs)
+        e64.sync()
+        el64 = time.perf_counter() - t1
+        f64_leg = {"value": n_f_total * args.steps / el64, "unit": "collocation-points/s",
+                   "ms_per_step": 1e3 * el64 / args.steps, "dtype": "f64", "kernel_path": e64.kernel_path()}
+        e64.close()
+
     if rank == 0:
         n_f_local = shard(n_f_total, world, 0)[1]
         n_u_local = shard(100, world, 0)[1]
@@ -220,6 +247,7 @@ def main():
                                    "iterations, canonical glorot init" % (args.nf_per_gpu, k_adam, k_lbfgs),
                        "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world,
                        "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
+            "float64_leg": f64_leg,
             "final_l2_error": final_err,
             "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
