@@ -67,23 +67,27 @@ class BurgersInformedNN(NeuralNetwork):
         return u_star, f_star
 
 
-if __name__ == "__main__":
-    path = os.path.join(_root, eqnPath, "data", "burgers_shock.mat")
-    x, t, X, T, Exact_u, X_star, u_star, \
-        X_u_train, u_train, X_f, ub, lb = prep_data(path, hp["N_u"], hp["N_f"], noise=0.0)
+def relative_l2(reference, prediction):
+    return np.linalg.norm(reference - prediction, 2) / np.linalg.norm(reference, 2)
+
+
+def run(hp):
+    """The script body of the reference (:100-127): data, model, training, prediction, figure."""
+    data_file = os.path.join(_root, eqnPath, "data", "burgers_shock.mat")
+    (x, t, X, T, Exact_u, X_star, u_star,
+     X_u_train, u_train, X_f, ub, lb) = prep_data(data_file, hp["N_u"], hp["N_f"], noise=0.0)
 
     logger = Logger(hp)
     pinn = BurgersInformedNN(hp, logger, X_f, ub, lb, nu=0.01 / np.pi)
-
-    def error():
-        u_pred, _ = pinn.predict(X_star)
-        return np.linalg.norm(u_star - u_pred, 2) / np.linalg.norm(u_star, 2)
-
-    logger.set_error_fn(error)
+    logger.set_error_fn(lambda: relative_l2(u_star, pinn.predict(X_star)[0]))
     pinn.fit(X_u_train, u_train)
 
-    u_pred, _ = pinn.predict(X_star)
+    u_pred = pinn.predict(X_star)[0]
     if not os.environ.get("PINN_NO_PLOT"):
-        plot_inf_cont_results(X_star, u_pred.flatten(), X_u_train, u_train,
-                              Exact_u, X, T, x, t, save_path=os.path.join(_root, eqnPath),
-                              save_hp=hp)
+        plot_inf_cont_results(X_star, u_pred.flatten(), X_u_train, u_train, Exact_u, X, T, x, t,
+                              save_path=os.path.join(_root, eqnPath), save_hp=hp)
+    return pinn
+
+
+if __name__ == "__main__":
+    run(hp)

@@ -26,54 +26,74 @@ def _engine_banner():
         return "pinn_hip unavailable (%s)" % exc, "none", False
 
 
+class _Clock(object):
+    """Two stopwatches: since construction ("MM:SS") and since the previous logged line ("SS.f")."""
+
+    def __init__(self):
+        self.t0 = self.t_last = time.time()
+
+    @staticmethod
+    def _fmt(seconds, pattern):
+        return datetime.fromtimestamp(seconds).strftime(pattern)
+
+    def total(self):
+        return self._fmt(time.time() - self.t0, "%M:%S")
+
+    def lap(self):
+        now = time.time()
+        text = self._fmt(now - self.t_last, "%S.%f")[:-5]
+        self.t_last = now
+        return text
+
+
+_EPOCH_LINE = "{tag} = {epoch:6d}  elapsed = {total} (+{lap})  loss = {loss:.4e}  {custom}"
+_END_LINE = "Training finished (epoch {epoch}): duration = {total}  error = {err:.4e}  {custom}"
+
+
 class Logger(object):
     def __init__(self, hp):
-        print("Hyperparameters:")
-        print(json.dumps(hp, indent=2))
-        print()
-
+        banner = ["Hyperparameters:", json.dumps(hp, indent=2), ""]
         engine, device, on_gpu = _engine_banner()
-        print("Engine: {}".format(engine))
-        print("Device: {}".format(device))
-        print("GPU-accerelated: {}".format(on_gpu))
-
-        self.start_time = time.time()
-        self.prev_time = self.start_time
+        banner += ["Engine: %s" % engine, "Device: %s" % device, "GPU-accerelated: %s" % on_gpu]
+        print("\n".join(banner))
+        self._clock = _Clock()
         self.frequency = hp["log_frequency"]
+        self.error_fn = None
+        self.model = None
+
+    # the reference exposes its two time stamps as attributes; keep them readable / settable
+    start_time = property(lambda self: self._clock.t0, lambda self, v: setattr(self._clock, "t0", v))
+    prev_time = property(lambda self: self._clock.t_last, lambda self, v: setattr(self._clock, "t_last", v))
 
     def get_epoch_duration(self):
-        now = time.time()
-        stamp = datetime.fromtimestamp(now - self.prev_time).strftime("%S.%f")[:-5]
-        self.prev_time = now
-        return stamp
+        return self._clock.lap()
 
     def get_elapsed(self):
-        return datetime.fromtimestamp(time.time() - self.start_time).strftime("%M:%S")
-
-    def get_error_u(self):
-        return self.error_fn()
+        return self._clock.total()
 
     def set_error_fn(self, error_fn):
         self.error_fn = error_fn
 
+    def get_error_u(self):
+        return self.error_fn()
+
     def log_train_start(self, model, model_description=False):
-        print("\nTraining started")
-        print("================")
         self.model = model
+        print("\nTraining started\n================")
         if model_description:
             print(model.summary())
-
-    def log_train_epoch(self, epoch, loss, custom="", is_iter=False):
-        if epoch % self.frequency != 0:
-            return
-        tag = "nt_epoch" if is_iter else "tf_epoch"
-        print("%s = %6d  elapsed = %s (+%s)  loss = %.4e  %s" % (
-            tag, epoch, self.get_elapsed(), self.get_epoch_duration(), float(loss), custom))
 
     def log_train_opt(self, name):
         print("-- Starting %s optimization --" % name)
 
+    def log_train_epoch(self, epoch, loss, custom="", is_iter=False):
+        if epoch % self.frequency:
+            return
+        print(_EPOCH_LINE.format(tag="nt_epoch" if is_iter else "tf_epoch", epoch=int(epoch),
+                                 total=self._clock.total(), lap=self._clock.lap(), loss=float(loss),
+                                 custom=custom))
+
     def log_train_end(self, epoch, custom=""):
         print("==================")
-        print("Training finished (epoch %s): duration = %s  error = %.4e  %s" % (
-            epoch, self.get_elapsed(), float(self.get_error_u()), custom))
+        print(_END_LINE.format(epoch=epoch, total=self._clock.total(), err=float(self.get_error_u()),
+                               custom=custom))

@@ -239,14 +239,14 @@ class NeuralNetwork(object):
         self._bind(X_u, u)
         freq = max(int(self.logger.frequency), 1)
         epoch = 0
-        k = self._resample_every if self._engine.n_f > 0 else 0
+        every = self._resample_every if self._engine.n_f > 0 else 0
         while epoch < self.tf_epochs:
-            if k and epoch > 0 and epoch % k == 0:
+            if every and epoch > 0 and epoch % every == 0:
                 self._engine.lhs_collocation(self._engine.n_f, self._resample_seed + epoch)
             # run up to and including the next epoch that is logged, then sync once
             stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
-            if k:
-                stop = min(stop, (epoch // k + 1) * k)
+            if every:
+                stop = min(stop, (epoch // every + 1) * every)
             losses = self._engine.adam_run(stop - epoch)
             for k, loss_value in enumerate(losses):
                 last = epoch + k == stop - 1     # the weights on the device are those after this epoch
