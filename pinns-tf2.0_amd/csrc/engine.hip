@@ -333,12 +333,10 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       bool fwd_done = false;
       if constexpr (sizeof(real) == 4) {
         if (c->path == 3) {
-          static bool attr = false;
-          if (!attr) {
+          static unsigned long long attr = 0;
+          if (first_call_on_device(attr))
             HIPCHK(hipFuncSetAttribute((const void*)k_wide_fwd<100, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)wide_lds_bytes<100>()));
-            attr = true;
-          }
           const int n_groups = pts / 16;
           const int wg = n_groups < c->n_cu ? n_groups : c->n_cu;
           hipLaunchKernelGGL((k_wide_fwd<100, 2>), dim3(wg), dim3(256), wide_lds_bytes<100>(), c->stream, c->nd,
@@ -357,12 +355,10 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       bool bwd_done = false;
       if constexpr (sizeof(real) == 4 && PDE == 2) {
         if (c->path == 3) {
-          static bool attr = false;
-          if (!attr) {
+          static unsigned long long attr = 0;
+          if (first_call_on_device(attr))
             HIPCHK(hipFuncSetAttribute((const void*)k_wide_bwd<100, 2, 2, 4>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes<100>()));
-            attr = true;
-          }
           const int n_groups = pts / 16;
           const int wg = n_groups < c->n_cu ? n_groups : c->n_cu;
           hipLaunchKernelGGL((k_wide_bwd<100, 2, 2, 4>), dim3(wg), dim3(256), wide_lds_bytes<100>(), c->stream,
@@ -479,15 +475,14 @@ static int disc_ensure(pinn_ctx* c) {
 
 template <typename real, int NT>
 static int disc_set_lds() {
-  static bool done = false;
-  if (done) return 0;
+  static unsigned long long done = 0;
+  if (!first_call_on_device(done)) return 0;
   HIPCHK(hipFuncSetAttribute((const void*)k_disc_fwd<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)disc_fwd_lds<NT>(sizeof(real))));
   HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_out<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)disc_out_lds<NT>(sizeof(real))));
   HIPCHK(hipFuncSetAttribute((const void*)k_disc_bwd_hidden<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)disc_hid_lds<NT>(sizeof(real))));
-  done = true;
   return 0;
 }
 

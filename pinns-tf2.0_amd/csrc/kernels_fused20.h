@@ -385,12 +385,14 @@ inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, 
                           real nu, vec4<real>* S, real* part, int R, hipStream_t stream,
                           long long* stamps = nullptr) {
   const size_t lds = fused20_lds_bytes<real>(nd.n_hidden);
-  static size_t attr_set = 0;
-  if (attr_set < lds) {
+  static size_t attr_set[64] = {};                 // per device: the attribute belongs to the device's code object
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (attr_set[dev & 63] < lds) {
     hipError_t e = hipFuncSetAttribute((const void*)k_fused20<real, PDE>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = lds;
+    attr_set[dev & 63] = lds;
   }
   hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
                      xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R, stamps);

@@ -476,12 +476,11 @@ inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th
                            float sx, float st, float nu, float* part, int R, int n_wg,
                            hipStream_t stream, long long* stamps = nullptr) {
   const size_t lds = fused20m_lds_bytes(H);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_call_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)k_fused20m<PDE, H>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
                      ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);

@@ -8,6 +8,17 @@
 
 namespace pinn {
 
+// Host side: kernel attributes (dynamic LDS size) are per device, so "set once" flags are per device too.
+// True exactly once per (flag, current device).
+inline bool first_call_on_device(unsigned long long& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 template <typename T> struct alignas(4 * sizeof(T)) vec4 { T x, y, z, w; };
 
 // DPP control words (gfx9 encoding)
