@@ -139,9 +139,10 @@ def main():
     eng = make_engine(args.dtype, local_rank, X_f, X_u, u, lb, ub, world, rank, n_f_total, 100)
     if args.kernel_path >= 0:
         eng.set_kernel_path(args.kernel_path)
+    comm_mode = "none"
     if world > 1:
         from pinn_native.parallel import init_engine_comm
-        init_engine_comm(eng, dist, world, rank)
+        comm_mode = init_engine_comm(eng, dist, world, rank)     # "mailbox" if every rank's self-test passed, else "rccl"
 
     def barrier():
         eng.sync()
@@ -245,7 +246,7 @@ def main():
             "config": {"workload": "1D Burgers continuous inference (BASELINE configs[1]): 8x20 tanh "
                                    "MLP, N_u=100, N_f=%d per GPU (LHS, seed 1234), %d Adam + %d L-BFGS "
                                    "iterations, canonical glorot init" % (args.nf_per_gpu, k_adam, k_lbfgs),
-                       "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world,
+                       "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world, "allreduce": comm_mode,
                        "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
             "float64_leg": f64_leg,
             "final_l2_error": final_err,

@@ -137,6 +137,20 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n);
  * out-of-band channel; every rank then calls pinn_comm_init. */
 int pinn_comm_unique_id(char* id128);
 int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank);
+/* Low-latency alternative to the RCCL call for the [P+4] vector: every rank maps every peer's mailbox (hipIpc) and
+ * the reduction kernel itself stores, signals, waits and adds in rank order (csrc/kernels_xgmi.h).  Protocol:
+ *   1. every rank: pinn_comm_xgmi_export(n_ranks, rank, handle64)        -> 64-byte hipIpcMemHandle_t
+ *   2. ship all handles to all ranks (out of band, like the RCCL id), rank-major [n_ranks][64]
+ *   3. every rank: pinn_comm_xgmi_attach(handles, n_ranks, &mapped)      -> mapped = 1 if every peer mailbox is mapped
+ *   4. only if mapped on ALL ranks (agreed out of band): pinn_comm_xgmi_selftest(&ok) everywhere -- a few exchange
+ *      rounds on integer-valued vectors checked against the closed-form sum, bounded waits (5 s)
+ *   5. if ok on ALL ranks: pinn_comm_set_mode(2) everywhere; otherwise stay on / return to RCCL (mode 1).
+ * pinn_comm_get_mode: 0 no communicator, 1 RCCL, 2 mailboxes.  Works without an RCCL communicator too. */
+int pinn_comm_xgmi_export(pinn_ctx* c, int n_ranks, int rank, char* handle64);
+int pinn_comm_xgmi_attach(pinn_ctx* c, const char* handles, int n_handles, int* mapped_ok);
+int pinn_comm_xgmi_selftest(pinn_ctx* c, int* ok);
+int pinn_comm_set_mode(pinn_ctx* c, int mode);
+int pinn_comm_get_mode(pinn_ctx* c, int* mode);
 
 /* Measurement: bracket launches of the dominant kernel (the loss+grad kernels) with hipEvents
  * on the engine's stream.  An event record costs ~5 us on the GPU timeline, so only one

@@ -20,6 +20,7 @@
 #include "kernels_optim.h"
 #include "kernels_disc.h"
 #include "kernels_sampling.h"
+#include "kernels_xgmi.h"
 
 using namespace pinn;
 
@@ -134,6 +135,15 @@ struct pinn_ctx {
   // RCCL
   ncclComm_t comm = nullptr;
   int n_ranks = 1, rank = 0;
+  // peer-mapped mailbox all-reduce (kernels_xgmi.h); comm_mode: 0 none, 1 RCCL, 2 mailboxes
+  struct {
+    void* box = nullptr;                      // this rank's mailbox (uncached, exported through hipIpc)
+    void* opened[XG_MAX_RANKS] = {};          // peers' mailboxes as mapped here (nullptr for own rank)
+    XgPeers peers{};
+    int* err = nullptr;
+    unsigned int seq = 0;                     // evaluation counter; 0 is never used (an all-zero mailbox is invalid)
+    bool attached = false, on = false;
+  } xg;
 
   // per-wave phase timeline of the fused kernel (profiling build only)
   long long* stamps = nullptr;
@@ -291,6 +301,22 @@ struct AdamFuse {          // single-GPU Adam step applied by the reduction kern
 template <typename real>
 static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
   const dim3 rgrid((c->R + RED_COLS - 1) / RED_COLS);
+  if (c->xg.on) {   // rows -> vector -> every peer's mailbox -> sum over ranks (-> Adam), one launch
+    if (++c->xg.seq == 0) c->xg.seq = 2;          // 32-bit wrap: skip 0, keep the parity alternating
+    const unsigned int seq = c->xg.seq;
+    if (af)
+      hipLaunchKernelGGL((k_reduce_xgmi<real, true>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
+                         n_rows, c->R, c->gl, c->xg.peers, seq, XG_TIMEOUT_TICKS, c->xg.err, c->nd.n_theta, c->theta,
+                         (real*)c->theta_r, c->adam_m, c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd,
+                         c->img);
+    else
+      hipLaunchKernelGGL((k_reduce_xgmi<real, false>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
+                         n_rows, c->R, c->gl, c->xg.peers, seq, XG_TIMEOUT_TICKS, c->xg.err, 0, (double*)nullptr,
+                         (real*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 0.0, 0.0, 0.0, (double*)nullptr,
+                         c->nd, (float*)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
@@ -535,7 +561,8 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
   else if (c->dtype == PINN_F64) { DISPATCH(double) } else { DISPATCH(float) }
 #undef DISPATCH
   if (rc) return rc;
-  if (c->comm) NCCLCHK(ncclAllReduce(c->gl, c->gl, (size_t)c->R, ncclDouble, ncclSum, c->comm, c->stream));
+  if (c->comm && !c->xg.on)
+    NCCLCHK(ncclAllReduce(c->gl, c->gl, (size_t)c->R, ncclDouble, ncclSum, c->comm, c->stream));
   if (ev4) { HIPCHK(hipEventRecord(ev4[3], c->stream)); c->ev_used++; }
   return 0;
 }
@@ -588,6 +615,64 @@ static int disc_predict_any(pinn_ctx* c, int mode, int set, const double* x, int
   if (c->dtype == PINN_F64) return disc_predict_impl<double, 4>(c, mode, set, x, n, out);
   return c->nd.width <= 64 ? disc_predict_impl<float, 4>(c, mode, set, x, n, out)
                            : disc_predict_impl<float, 8>(c, mode, set, x, n, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// mailbox all-reduce: set-up, self-test, tear-down (kernels_xgmi.h)
+// ------------------------------------------------------------------------------------------
+static void xg_release(pinn_ctx* c) {
+  for (int r = 0; r < XG_MAX_RANKS; ++r)
+    if (c->xg.opened[r]) { (void)hipIpcCloseMemHandle(c->xg.opened[r]); c->xg.opened[r] = nullptr; }
+  if (c->xg.box) { (void)hipFree(c->xg.box); c->xg.box = nullptr; }
+  if (c->xg.err) { (void)hipFree(c->xg.err); c->xg.err = nullptr; }
+  c->xg.attached = c->xg.on = false;
+  c->xg.seq = 0;
+}
+
+// an error raised inside a mailbox kernel (a peer that never delivered) surfaces at the next host sync
+static int xg_check(pinn_ctx* c) {
+  if (!c->xg.on) return 0;
+  int e = 0;
+  HIPCHK(hipMemcpyAsync(&e, c->xg.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (e) return fail(PINN_ECOMM, "mailbox all-reduce: a peer did not deliver its vector within the time limit");
+  return 0;
+}
+
+// T rounds on integer-valued vectors (exact in float64, so the expected sum is known in closed form)
+static int xg_self_test(pinn_ctx* c, int* ok) {
+  *ok = 0;
+  const int R = c->R, n = c->xg.peers.n_ranks, me = c->xg.peers.rank;
+  double *vec = nullptr, *out = nullptr;
+  if (dev_alloc(&vec, (size_t)R * 8) || dev_alloc(&out, (size_t)R * 8)) return PINN_EHIP;
+  std::vector<double> h(R), got(R);
+  bool good = true;
+  double* const gl_saved = c->gl;
+  for (int round = 0; round < 6 && good; ++round) {
+    for (int i = 0; i < R; ++i) h[i] = (double)((me + 1) * 1000 + (i % 97) + round);
+    HIPCHK(hipMemcpyAsync(vec, h.data(), (size_t)R * 8, hipMemcpyHostToDevice, c->stream));
+    if (++c->xg.seq == 0) c->xg.seq = 2;
+    const unsigned int seq = c->xg.seq;
+    hipLaunchKernelGGL((k_reduce_xgmi<double, false>), dim3((R + RED_COLS - 1) / RED_COLS), dim3(RED_THREADS), 0,
+                       c->stream, (const double*)vec, 1, R, out, c->xg.peers, seq, XG_TEST_TIMEOUT_TICKS, c->xg.err, 0,
+                       (double*)nullptr, (double*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 0.0, 0.0, 0.0,
+                       (double*)nullptr, c->nd, (float*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(got.data(), out, (size_t)R * 8, hipMemcpyDeviceToHost, c->stream));
+    int e = 0;
+    HIPCHK(hipMemcpyAsync(&e, c->xg.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (e) good = false;
+    for (int i = 0; i < R && good; ++i) {
+      const double want = 1000.0 * n * (n + 1) / 2.0 + (double)n * ((i % 97) + round);
+      if (got[i] != want) good = false;
+    }
+  }
+  (void)gl_saved;
+  (void)hipFree(vec); (void)hipFree(out);
+  if (!good) HIPCHK(hipMemsetAsync(c->xg.err, 0, sizeof(int), c->stream));
+  *ok = good ? 1 : 0;
+  return 0;
 }
 
 static int cast_weights(pinn_ctx* c) {
@@ -706,6 +791,7 @@ int pinn_destroy(pinn_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  xg_release(c);
   void* ptrs[] = {c->xs, c->ts, c->tgt, c->theta, c->gl, c->adam_m, c->adam_v, c->theta_r, c->S,
                   c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
@@ -827,6 +913,7 @@ int pinn_loss_grad(pinn_ctx* c, double* loss, double* grad, double* terms) {
   std::vector<double> h(c->R);
   HIPCHK(hipMemcpyAsync(h.data(), c->gl, (size_t)c->R * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if ((rc = xg_check(c))) return rc;
   const int P = c->nd.n_theta;
   if (loss) *loss = h[P] + h[P + 1] + h[P + 2];
   if (terms) { terms[0] = h[P]; terms[1] = h[P + 1]; terms[2] = h[P + 2]; }
@@ -860,7 +947,7 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
     const double t = (double)c->adam_t;
     const double alpha = c->lr * std::sqrt(1.0 - std::pow(c->b2, t)) / (1.0 - std::pow(c->b1, t));
     double* slot = losses ? c->loss_hist + (size_t)3 * s : nullptr;
-    if (!c->comm) {                               // reduction + update in one kernel
+    if (!c->comm || c->xg.on) {                   // reduction (+ mailbox all-reduce) + update in one kernel
       const AdamFuse af{alpha, slot};
       int rc = eval_loss_grad(c, &af);
       if (rc) return rc;
@@ -1148,10 +1235,80 @@ int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank) {
   REQUIRE(c && id128 && n_ranks >= 1 && rank >= 0 && rank < n_ranks, "bad communicator arguments");
   HIPCHK(hipSetDevice(c->device));
   if (c->comm) { ncclCommDestroy(c->comm); c->comm = nullptr; }
+  xg_release(c);
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   NCCLCHK(ncclCommInitRank(&c->comm, n_ranks, id, rank));
   c->n_ranks = n_ranks; c->rank = rank;
+  return 0;
+}
+
+int pinn_comm_xgmi_export(pinn_ctx* c, int n_ranks, int rank, char* handle64) {
+  REQUIRE(c && handle64 && n_ranks >= 1 && n_ranks <= XG_MAX_RANKS && rank >= 0 && rank < n_ranks,
+          "bad arguments (at most %d ranks)", XG_MAX_RANKS);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  HIPCHK(hipSetDevice(c->device));
+  xg_release(c);
+  const int Rp = (c->R + 63) / 64 * 64;
+  const size_t bytes = xg_box_bytes(n_ranks, Rp);
+  hipError_t e = hipExtMallocWithFlags(&c->xg.box, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) { c->xg.box = nullptr; return fail(PINN_EHIP, "mailbox allocation: %s", hipGetErrorString(e)); }
+  HIPCHK(hipMemset(c->xg.box, 0, bytes));
+  if (dev_alloc(&c->xg.err, sizeof(int))) return PINN_EHIP;
+  HIPCHK(hipMemset(c->xg.err, 0, sizeof(int)));
+  HIPCHK(hipDeviceSynchronize());
+  c->xg.peers = XgPeers{};
+  c->xg.peers.n_ranks = n_ranks; c->xg.peers.rank = rank; c->xg.peers.Rp = Rp;
+  hipIpcMemHandle_t h;
+  e = hipIpcGetMemHandle(&h, c->xg.box);
+  if (e != hipSuccess) { xg_release(c); return fail(PINN_EHIP, "hipIpcGetMemHandle: %s", hipGetErrorString(e)); }
+  memcpy(handle64, &h, 64);
+  return 0;
+}
+
+int pinn_comm_xgmi_attach(pinn_ctx* c, const char* handles, int n_handles, int* mapped_ok) {
+  REQUIRE(c && handles && mapped_ok, "null");
+  REQUIRE(c->xg.box && n_handles == c->xg.peers.n_ranks, "pinn_comm_xgmi_export first; one handle per rank");
+  HIPCHK(hipSetDevice(c->device));
+  int* self_test_ok = mapped_ok;
+  *self_test_ok = 0;
+  const int n = c->xg.peers.n_ranks, me = c->xg.peers.rank;
+  // (a workgroup of the reduction kernel waits only for remote stores, never for another local workgroup, so the
+  //  grid needs no co-residency guarantee)
+  for (int r = 0; r < n; ++r) {
+    void* base = c->xg.box;
+    if (r != me) {
+      hipIpcMemHandle_t h;
+      memcpy(&h, handles + (size_t)64 * r, 64);
+      hipError_t e = hipIpcOpenMemHandle(&c->xg.opened[r], h, hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { c->xg.opened[r] = nullptr; (void)hipGetLastError(); return 0; }   // stay on RCCL
+      base = c->xg.opened[r];
+    }
+    c->xg.peers.box[r] = (xg_line_t*)base;
+  }
+  c->xg.attached = true;
+  *mapped_ok = 1;
+  return 0;
+}
+
+int pinn_comm_xgmi_selftest(pinn_ctx* c, int* ok) {
+  REQUIRE(c && ok, "null");
+  REQUIRE(c->xg.attached, "pinn_comm_xgmi_attach first");
+  HIPCHK(hipSetDevice(c->device));
+  return xg_self_test(c, ok);
+}
+
+int pinn_comm_set_mode(pinn_ctx* c, int mode) {
+  REQUIRE(c && (mode == 1 || mode == 2), "mode must be 1 (RCCL) or 2 (mailboxes)");
+  if (mode == 2) REQUIRE(c->xg.attached, "mailboxes are not attached (pinn_comm_xgmi_attach)");
+  if (mode == 1) REQUIRE(c->comm || c->xg.attached, "no communicator");
+  c->xg.on = mode == 2;
+  return 0;
+}
+
+int pinn_comm_get_mode(pinn_ctx* c, int* mode) {
+  REQUIRE(c && mode, "null");
+  *mode = c->xg.on ? 2 : c->comm ? 1 : 0;
   return 0;
 }
 
@@ -1204,7 +1361,7 @@ int pinn_sync(pinn_ctx* c) {
   REQUIRE(c, "null");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  return xg_check(c);
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {

@@ -1,0 +1,103 @@
+// kernels_xgmi.h -- one-shot all-reduce of the [P+4] float64 gradient/loss vector through peer-mapped mailboxes.
+//
+// The exchange step of the data-parallel path is one 24 KB vector per evaluation: far below the
+// size where a ring or tree pays off, and on the critical path of every optimiser step.  xGMI is point-to-point,
+// so the latency-optimal schedule is the trivial one: every rank stores its vector straight into a slot of every
+// peer's mailbox (7 concurrent streams, one per link), and every rank adds the slots of its own mailbox in rank
+// order.  That is one kernel -- the same launch that reduces the per-workgroup partial rows, and for Adam also the
+// one that applies the update -- instead of reduce -> ncclAllReduce -> update, and since every rank adds in the
+// same order the replicas stay bit-identical.
+//
+// No fence, no counter, no separate flag: each float64 travels as one 16-byte line {lo32, seq32, hi32, seq32}
+// written by a single global_store_dwordx4 (the "LL" idea of NCCL/RCCL's low-latency protocol): a line is valid
+// when both sequence words equal the evaluation's sequence number, whatever order or granularity (>= 8 bytes) the
+// fabric delivers the writes in.  The consumer thread of column c polls the n_ranks - 1 lines of column c in its
+// own mailbox (its own contribution stays in a register) with cache-bypassing loads.
+//
+// Mailbox (hipExtMallocWithFlags(hipDeviceMallocUncached), mapped into every peer with hipIpc):
+//   line[2][n_ranks][Rp]  16 bytes each; [parity = seq & 1][source rank][column].  A rank can be at most one
+//   evaluation ahead of a peer (it needs the peer's lines of evaluation s to finish s), so two generations
+//   never collide.  Waiting is bounded by wall_clock64: a lost peer becomes an error code, never a hang.
+// RCCL stays the fallback (pinn_comm_set_mode) and the mailboxes are switched on only after a self-test passed
+// on every rank.
+#pragma once
+#include "kernels_optim.h"
+
+namespace pinn {
+
+constexpr int XG_MAX_RANKS = 16;
+constexpr long long XG_TIMEOUT_TICKS = 30ll * 100000000ll;      // 30 s of the 100 MHz wall clock (training)
+constexpr long long XG_TEST_TIMEOUT_TICKS = 5ll * 100000000ll;  // 5 s (attach-time self-test)
+
+typedef unsigned int xg_line_t __attribute__((ext_vector_type(4)));
+
+struct XgPeers {
+  xg_line_t* box[XG_MAX_RANKS];               // base of peer r's mailbox as mapped on this rank
+  int n_ranks, rank, Rp;                      // Rp = slot pitch in lines
+};
+
+inline size_t xg_box_bytes(int n_ranks, int Rp) { return (size_t)2 * n_ranks * Rp * sizeof(xg_line_t); }
+
+// system-coherent, cache-bypassing 16-byte accesses
+__device__ __forceinline__ void xg_store(xg_line_t* dst, xg_line_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ xg_line_t xg_load(const xg_line_t* src) {
+  xg_line_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+  return v;
+}
+
+template <typename real, bool ADAM>
+__global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restrict__ part, int n_rows, int R,
+                                                             double* __restrict__ gl, XgPeers px,
+                                                             unsigned int seq, long long timeout_ticks,
+                                                             int* __restrict__ err, int n, double* __restrict__ theta,
+                                                             real* __restrict__ theta_r, double* __restrict__ m,
+                                                             double* __restrict__ v, double alpha, double b1, double b2,
+                                                             double eps, double* __restrict__ loss3, NetDesc nd,
+                                                             float* __restrict__ img) {
+  __shared__ double sh[RED_SLICES][RED_COLS];
+  const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  const double g = reduce_column(part, n_rows, R, c, q, sh);
+  if (q != 0 || c >= R) return;
+  const int par = (int)(seq & 1u), nr = px.n_ranks, me = px.rank;
+  {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(g);
+    const xg_line_t line = {(unsigned int)bits, seq, (unsigned int)(bits >> 32), seq};
+    for (int k = 1; k < nr; ++k) {            // start with the next rank: spreads the traffic over the links
+      const int r = (me + k) % nr;
+      xg_store(px.box[r] + (size_t)(par * nr + me) * px.Rp + c, line);
+    }
+  }
+  double tot = 0;
+  const long long t0 = wall_clock64();
+  for (int r = 0; r < nr; ++r) {
+    if (r == me) { tot += g; continue; }
+    const xg_line_t* src = px.box[me] + (size_t)(par * nr + r) * px.Rp + c;
+    xg_line_t line = xg_load(src);
+    while (line.y != seq || line.w != seq) {
+      if (wall_clock64() - t0 > timeout_ticks) { atomicExch(err, 1); break; }
+      __builtin_amdgcn_s_sleep(1);
+      line = xg_load(src);
+    }
+    tot += __longlong_as_double((long long)(((unsigned long long)line.z << 32) | line.x));
+  }
+  gl[c] = tot;
+  if (ADAM) {
+    if (c < n) {
+      const double mi = m[c] + (1.0 - b1) * (tot - m[c]);
+      const double vi = v[c] + (1.0 - b2) * (tot * tot - v[c]);
+      m[c] = mi;
+      v[c] = vi;
+      const double t = theta[c] - alpha * mi / (sqrt(vi) + eps);
+      theta[c] = t;
+      theta_r[c] = (real)t;
+      pack_store_any(nd, img, c, (float)t);
+    } else if (loss3 && c < n + 3) {
+      loss3[c - n] = tot;
+    }
+  }
+}
+
+}  // namespace pinn

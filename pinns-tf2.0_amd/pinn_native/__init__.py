@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
 SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_wide.h",
-           "kernels_disc.h", "kernels_sampling.h", "kernels_optim.h", "wave.h"]
+           "kernels_disc.h", "kernels_sampling.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
 PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2, "burgers_disc": 3, "burgers_disc_ide": 4}
@@ -97,6 +97,11 @@ _SIGNATURES = {
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_comm_xgmi_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
+    "pinn_comm_xgmi_attach": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, _c_int_p]),
+    "pinn_comm_xgmi_selftest": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
+    "pinn_comm_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pinn_comm_get_mode": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
     "pinn_lhs_collocation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                             ctypes.c_uint64]),
     "pinn_get_collocation": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
@@ -353,6 +358,31 @@ class Engine(object):
         self._check(self._lib.pinn_comm_init(self._h, bytes(unique_id), int(n_ranks), int(rank)))
 
     # ---- measurement -----------------------------------------------------------------------
+    def comm_xgmi_export(self, n_ranks, rank):
+        buf = ctypes.create_string_buffer(64)
+        self._check(self._lib.pinn_comm_xgmi_export(self._h, int(n_ranks), int(rank), buf))
+        return buf.raw
+
+    def comm_xgmi_attach(self, handles):
+        """handles: list of the 64-byte handles of all ranks, rank order.  True if every peer mailbox got mapped."""
+        blob = b"".join(handles)
+        ok = ctypes.c_int(0)
+        self._check(self._lib.pinn_comm_xgmi_attach(self._h, blob, len(handles), ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def comm_xgmi_selftest(self):
+        ok = ctypes.c_int(0)
+        self._check(self._lib.pinn_comm_xgmi_selftest(self._h, ctypes.byref(ok)))
+        return bool(ok.value)
+
+    def comm_set_mode(self, mode):
+        self._check(self._lib.pinn_comm_set_mode(self._h, {"rccl": 1, "mailbox": 2}.get(mode, mode)))
+
+    def comm_mode(self):
+        m = ctypes.c_int(0)
+        self._check(self._lib.pinn_comm_get_mode(self._h, ctypes.byref(m)))
+        return {0: "none", 1: "rccl", 2: "mailbox"}[m.value]
+
     def timing_enable(self, max_evals, every=1):
         self._check(self._lib.pinn_timing_enable(self._h, int(max_evals), int(every)))
 

@@ -35,10 +35,51 @@ def attach_shards(engine, world, rank, X_f=None, X_u=None, u=None, X_lb=None, X_
         engine.set_boundary(X_lb[lo:hi], X_ub[lo:hi], n_total=len(X_lb))
 
 
-def init_engine_comm(engine, dist, world, rank):
-    """Create the RCCL communicator of `engine`: rank 0 draws the unique id, torch.distributed
-    (any backend; gloo in this repo) broadcasts it, every rank joins."""
-    from . import Engine
-    box = [Engine.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    engine.comm_init(box[0], world, rank)
+def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
+    """Create the communicator of `engine`.
+
+    RCCL: rank 0 draws the unique id, torch.distributed (any backend; gloo in this repo) broadcasts it, every
+    rank joins.  Then, unless mailbox=False (default: on unless PINN_COMM=rccl), the peer-mapped mailbox
+    all-reduce of csrc/kernels_xgmi.h is set up on top: handles are all-gathered, every rank attaches and
+    self-tests, and the mailboxes are switched on only if *every* rank reports success -- otherwise all ranks
+    stay on RCCL.  Returns the mode in use ("rccl" or "mailbox")."""
+    from . import Engine, PinnNativeError
+    if rccl:
+        box = [Engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        engine.comm_init(box[0], world, rank)
+    if mailbox is None:
+        mailbox = os.environ.get("PINN_COMM", "mailbox").lower() != "rccl"
+    if not mailbox:
+        return "rccl"
+    try:
+        mine = engine.comm_xgmi_export(world, rank)
+    except PinnNativeError:
+        mine = None
+    def agree(flag):
+        votes = [None] * world
+        dist.all_gather_object(votes, bool(flag))
+        return all(votes), votes
+
+    handles = [None] * world
+    dist.all_gather_object(handles, mine)
+    ok = False
+    if all(h is not None for h in handles):
+        try:
+            ok = engine.comm_xgmi_attach(handles)
+        except PinnNativeError:
+            ok = False
+    mapped, verdicts = agree(ok)
+    if mapped:                       # every rank can reach every mailbox: exchange test vectors (bounded waits)
+        try:
+            ok = engine.comm_xgmi_selftest()
+        except PinnNativeError:
+            ok = False
+        mapped, verdicts = agree(ok)
+    if mapped:
+        engine.comm_set_mode("mailbox")
+        return "mailbox"
+    if rccl:
+        engine.comm_set_mode("rccl")
+        return "rccl"
+    raise RuntimeError("mailbox all-reduce unavailable and no RCCL communicator requested: %s" % verdicts)

@@ -56,3 +56,20 @@ def test_shards_with_global_denominators_add_up(burgers_sets, dtype, tol, path):
     assert abs(tot_l - l_full) / l_full < tol
     assert np.max(np.abs(tot_g - g_full)) / np.max(np.abs(g_full)) < tol
     eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_mailbox_allreduce_between_processes(world):
+    """csrc/kernels_xgmi.h end to end: `world` processes (all on device 0 -- the mailboxes are hipIpc-mapped across
+    processes exactly as across GPUs), sharded Burgers set, no RCCL: loss/gradient, fused Adam, L-BFGS and replica
+    bit-identity (tests/helpers/mailbox_ranks.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29500 + (os.getpid() + world) % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "helpers", "mailbox_ranks.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "MAILBOX_OK world=%d" % world in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
