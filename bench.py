@@ -116,7 +116,7 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("PINN_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # override: tests on one GPU
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run "
@@ -186,9 +186,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
 
-    # ---- accuracy leg (untimed): the reference's default schedule, final relative L2 error ----
+    # ---- accuracy leg (untimed): the reference's default schedule ON THE REFERENCE CONFIGURATION (N_f = 10000 in
+    # total, seed 1234 -- sharded over the ranks when N > 1), final relative L2 error of u over the 25600-point grid.
+    # The weak-scaling workload above has N x 10000 points, i.e. another training set with no reference value; and the
+    # schedule (Adam lr 0.03, L-BFGS without line search) is roundoff-chaotic, so the number is only comparable on the
+    # reference's own points.
     final_err = None
     if not args.no_final_error:
+        if n_f_total != 10000:
+            from pinn_native.parallel import attach_shards
+            np.random.seed(1234)
+            r2 = burgersutil.prep_data(os.path.join(PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, 10000, noise=0.0)
+            attach_shards(eng, world, rank, X_f=r2[9], X_u=r2[7], u=r2[8])
         eng.set_weights(w0)
         eng.adam_init(0.03, 0.9, 0.999, 1e-7)
         eng.adam_run(100, want_losses=False)
@@ -250,7 +259,8 @@ def main():
                        "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
             "float64_leg": f64_leg,
             "final_l2_error": final_err,
-            "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults",
+            "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults, on the "
+                                       "reference set N_f=10000 (sharded over the ranks); reference run: 0.2656",
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": pmc_traffic(args, world),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",

@@ -44,12 +44,15 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
     self-tests, and the mailboxes are switched on only if *every* rank reports success -- otherwise all ranks
     stay on RCCL.  Returns the mode in use ("rccl" or "mailbox")."""
     from . import Engine, PinnNativeError
+    policy = os.environ.get("PINN_COMM", "auto").lower()     # auto | rccl | mailbox-only (no RCCL communicator)
+    if policy == "mailbox-only":
+        rccl, mailbox = False, True
     if rccl:
         box = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         engine.comm_init(box[0], world, rank)
     if mailbox is None:
-        mailbox = os.environ.get("PINN_COMM", "mailbox").lower() != "rccl"
+        mailbox = policy != "rccl"
     if not mailbox:
         return "rccl"
     try:
