@@ -180,11 +180,17 @@ def main():
     elapsed = time.perf_counter() - t0
     tim = eng.timing_read()
     eng.timing_enable(0, 1)
+    replicas_identical = None
     if dist is not None:
+        import hashlib
         import torch
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
+        # every rank applied the same all-reduced gradients: the weight replicas must agree bit for bit
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.sha256(eng.get_weights().tobytes()).hexdigest())
+        replicas_identical = all(d == digests[0] for d in digests)
 
     # ---- accuracy leg (untimed): the reference's default schedule ON THE REFERENCE CONFIGURATION (N_f = 10000 in
     # total, seed 1234 -- sharded over the ranks when N > 1), final relative L2 error of u over the 25600-point grid.
@@ -256,6 +262,7 @@ def main():
                                    "MLP, N_u=100, N_f=%d per GPU (LHS, seed 1234), %d Adam + %d L-BFGS "
                                    "iterations, canonical glorot init" % (args.nf_per_gpu, k_adam, k_lbfgs),
                        "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world, "allreduce": comm_mode,
+                       "replicas_identical": replicas_identical,
                        "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
             "float64_leg": f64_leg,
             "final_l2_error": final_err,
