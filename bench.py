@@ -246,7 +246,8 @@ def main():
         flops_per_eval = 24.0 * M_W * n_f_local + 6.0 * M_W * n_u_local    # SURVEY.md 8(d), per rank
         # HIP events bracket the kernel on the engine's stream; an empty bracket already reads a few
         # microseconds, so the kernel duration is the bracket minus that calibrated constant
-        kernel_ms = max(tim["sweeps_ms"] - tim["empty_bracket_ms"], 0.0)
+        # (path 2: the events are attached to the kernel launch itself and read its begin/end timestamps -- exact)
+        kernel_ms = tim["fwd_ms"] if tim["kernel_exact"] else max(tim["sweeps_ms"] - tim["empty_bracket_ms"], 0.0)
         sweeps_s = kernel_ms * 1e-3
         achieved = flops_per_eval / sweeps_s / 1e12 if sweeps_s > 0 else None
         peak = PEAK_TFLOPS[args.dtype]
@@ -272,7 +273,7 @@ def main():
                          "frac": (achieved / peak) if achieved else None, "traffic": pmc_traffic(args, world),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                          "kernel": {2: "pinn::k_fused20m", 1: "pinn::k_fused20", 0: "pinn::k_forward+k_backward"}[eng.kernel_path()],
-                         "avg_launch_ms": kernel_ms, "event_bracket_ms": tim["sweeps_ms"],
+                         "avg_launch_ms": kernel_ms, "avg_launch_method": "hipExtLaunchKernelGGL start/stop events" if tim["kernel_exact"] else "event bracket minus empty bracket", "event_bracket_ms": tim["sweeps_ms"],
                          "empty_event_bracket_ms": tim["empty_bracket_ms"], "evals_timed": tim["n"],
                          "algorithmic_flop_per_launch": flops_per_eval,
                          "eval_ms_incl_reduce_allreduce": tim["eval_ms"]},

@@ -155,9 +155,11 @@ int pinn_comm_get_mode(pinn_ctx* c, int* mode);
 /* Measurement: bracket launches of the dominant kernel (the loss+grad kernels) with hipEvents
  * on the engine's stream.  An event record costs ~5 us on the GPU timeline, so only one
  * evaluation out of `every` is sampled (at most max_evals samples).  pinn_timing_read drains
- * them into avg_ms[4]: [0] forward sweep, [1] forward+reverse sweeps (the loss+grad kernel),
+ * them into avg_ms[5]: [0] forward sweep, [1] forward+reverse sweeps (the loss+grad kernel),
  * [2] whole evaluation, [3] what an EMPTY event bracket reads on this stream (calibrated at
- * enable time; subtract it from [0..2] to compare with rocprofv3 kernel durations);
+ * enable time; subtract it from [1..2] to compare with rocprofv3 kernel durations),
+ * [4] = 1 when [0] is the exact begin-to-end duration of the single loss+grad kernel (the events
+ * were attached to the launch itself, hipExtLaunchKernelGGL: kernel path 2) and needs no correction;
  * n = evaluations sampled. */
 int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);

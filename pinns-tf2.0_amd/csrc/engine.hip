@@ -335,16 +335,15 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const SetDesc sd = c->sd;
   const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
   const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
-  if (ev4) HIPCHK(hipEventRecord(ev4[0], c->stream));
+  if (ev4 && c->path != 2) HIPCHK(hipEventRecord(ev4[0], c->stream));
   if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2)
       rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
                                    (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
                                    (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
-                                   c->stream, c->stamps);
+                                   c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
     if (rc) return fail(PINN_EHIP, "fused20m launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
   } else if (c->path == 1) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
                                              (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
@@ -1353,6 +1352,7 @@ int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n) {
   *n = c->ev_used;
   const double k = c->ev_used ? 1.0 / c->ev_used : 0.0;
   avg_ms[0] = a * k; avg_ms[1] = b * k; avg_ms[2] = t * k; avg_ms[3] = c->ev_overhead_ms;
+  avg_ms[4] = c->path == 2 ? 1.0 : 0.0;
   c->ev_used = 0;
   return 0;
 }

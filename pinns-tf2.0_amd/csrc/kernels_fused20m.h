@@ -36,6 +36,7 @@
 // Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
 // the outer tape of utils/neuralnetwork.py:55-59.
 #pragma once
+#include <hip/hip_ext.h>
 #include "kernels_fused20.h"
 
 namespace pinn {
@@ -474,7 +475,8 @@ template <int PDE, int H>
 inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th, const float* img,
                            const float* xs, const float* ts, const float* tgt, float lbx, float lbt,
                            float sx, float st, float nu, float* part, int R, int n_wg,
-                           hipStream_t stream, long long* stamps = nullptr) {
+                           hipStream_t stream, long long* stamps = nullptr, hipEvent_t ev_start = nullptr,
+                           hipEvent_t ev_stop = nullptr) {
   const size_t lds = fused20m_lds_bytes(H);
   static unsigned long long attr_set = 0;
   if (first_call_on_device(attr_set)) {
@@ -482,8 +484,12 @@ inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
-                     ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
+  if (ev_start && ev_stop)      // the events take the kernel's own begin / end timestamps (what a profiler reports)
+    hipExtLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd,
+                          th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
+  else
+    hipLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
+                       ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
   return (int)hipGetLastError();
 }
 

@@ -387,11 +387,11 @@ class Engine(object):
         self._check(self._lib.pinn_timing_enable(self._h, int(max_evals), int(every)))
 
     def timing_read(self):
-        ms = np.zeros(4, dtype=np.float64)
+        ms = np.zeros(5, dtype=np.float64)
         n = ctypes.c_int(0)
         self._check(self._lib.pinn_timing_read(self._h, _dp(ms), ctypes.byref(n)))
         return {"fwd_ms": ms[0], "sweeps_ms": ms[1], "eval_ms": ms[2], "empty_bracket_ms": ms[3],
-                "n": n.value}
+                "kernel_exact": bool(ms[4]), "n": n.value}
 
     def sync(self):
         self._check(self._lib.pinn_sync(self._h))
