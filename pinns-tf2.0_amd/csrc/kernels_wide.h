@@ -47,7 +47,9 @@ struct WideCfg {
 template <int W>
 inline size_t wide_image_floats(int n_hidden) { return (size_t)(n_hidden - 1) * 2 * WideCfg<W>::IMG; }
 template <int W>
-inline size_t wide_lds_bytes() { return (size_t)2 * WideCfg<W>::IMG * 4 + (size_t)2 * WideCfg<W>::TILE * 16; }
+inline size_t wide_lds_bytes() {      // two weight buffers, two exchange tiles, output-layer partials [4 waves][16][8]
+  return (size_t)2 * WideCfg<W>::IMG * 4 + (size_t)2 * WideCfg<W>::TILE * 16 + 4 * 16 * 8 * 4;
+}
 
 __device__ __forceinline__ void pack_store_wide(const NetDesc& nd, float* __restrict__ img, int i, float v) {
   const int W = nd.width, WP = (W + 15) / 16 * 16, IMG = ((W + 1) * WP + 255) / 256 * 256;
@@ -150,12 +152,14 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
   float* const wbuf = reinterpret_cast<float*>(lds_raw);           // two weight buffers of IMG floats
   v4f* const T0 = reinterpret_cast<v4f*>(wbuf + 2 * C::IMG);
   v4f* const T1 = T0 + C::TILE;
+  float* const OP = reinterpret_cast<float*>(T1 + C::TILE);        // output-layer partials [4 waves][16 points][8]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   const int H = nd.n_hidden;
   v4f* const Sv = reinterpret_cast<v4f*>(S);
   v4f* const Ov = reinterpret_cast<v4f*>(O);
+  static_assert(NO <= 2, "output-layer partials are laid out for at most two outputs");
   int wcur = 0;                                                    // buffer holding the matrix about to be used
   wide_dma<W>(wbuf, img, wave, lane);                              // F_1
   wide_dma_drain();
@@ -172,17 +176,25 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
       w0t[t][r] = ok ? th[nd.off_w[0] + W + j] : 0.0f;
       b0[t][r] = ok ? th[nd.off_b[0] + j] : 0.0f;
     }
-  // output layer (wave 3: it owns a single feature tile): A[m][k] = WL[k][m] for m < NO
-  float aL[C::KS];
-  if (wave == 3) {
+  // output layer, K split over the four waves (wave w takes k-steps w, w+4, ...): A[m][k] = WL[k][m] for m < NO
+  constexpr int KSW = (C::KS + 3) / 4;
+  float aL[KSW];
 #pragma unroll
-    for (int s = 0; s < C::KS; ++s) aL[s] = n < NO ? th[nd.off_w[H] + (4 * s + g) * NO + n] : 0.0f;
+  for (int i = 0; i < KSW; ++i) {
+    const int s = wave + 4 * i;
+    aL[i] = (s < C::KS && n < NO) ? th[nd.off_w[H] + (4 * s + g) * NO + n] : 0.0f;
   }
   const float bL0 = th[nd.off_b[H]], bL1 = NO > 1 ? th[nd.off_b[H] + 1] : 0.0f;
 
+  float x_next = 0.0f, t_next = 0.0f;
+  if (blockIdx.x < n_groups) { x_next = xs[base + blockIdx.x * 16 + n]; t_next = ts[base + blockIdx.x * 16 + n]; }
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int lp = grp * 16 + n, pt = base + lp;
-    const float x = xs[pt], t = ts[pt];
+    const float x = x_next, t = t_next;
+    if (grp + (int)gridDim.x < n_groups) {       // the next group's inputs travel under this group's layers
+      x_next = xs[pt + 16 * gridDim.x];
+      t_next = ts[pt + 16 * gridDim.x];
+    }
     const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t - lbt, -1.0f);
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
@@ -234,25 +246,34 @@ __global__ __launch_bounds__(256) void k_wide_fwd(NetDesc nd, const float* __res
       v4f* tmp = Tin; Tin = Tout; Tout = tmp;
     }
     lds_barrier();                // last hidden layer's tile published
-    if (wave == 3) {              // linear output layer: rows m < NO of one 16-row tile
+    {                             // linear output layer: every wave its share of the k-steps, rows m < NO of one tile
       acc4 ao[4];
-      ao[0] = acc4{g == 0 ? bL0 : 0.0f, g == 0 ? bL1 : 0.0f, 0, 0};
+      ao[0] = acc4{(wave == 3 && g == 0) ? bL0 : 0.0f, (wave == 3 && g == 0) ? bL1 : 0.0f, 0, 0};
       ao[1] = ao[2] = ao[3] = acc4{0, 0, 0, 0};
       const v4f* __restrict__ b = Tin + g * C::TP + n;
 #pragma unroll
-      for (int s = 0; s < C::KS; ++s) {
-        const v4f B = b[4 * s * C::TP];
-        ao[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.x, ao[0], 0, 0, 0);
-        ao[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.y, ao[1], 0, 0, 0);
-        ao[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.z, ao[2], 0, 0, 0);
-        ao[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[s], B.w, ao[3], 0, 0, 0);
+      for (int i = 0; i < KSW; ++i) {
+        const int s = wave + 4 * i;
+        const v4f B = b[4 * (s < C::KS ? s : 0) * C::TP];       // out-of-range steps carry a zero A operand
+        ao[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[i], B.x, ao[0], 0, 0, 0);
+        ao[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[i], B.y, ao[1], 0, 0, 0);
+        ao[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[i], B.z, ao[2], 0, 0, 0);
+        ao[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(aL[i], B.w, ao[3], 0, 0, 0);
       }
-      if (g == 0) {
-        Ov[pt] = v4f{ao[0][0], ao[1][0], ao[2][0], ao[3][0]};
-        if (NO > 1) Ov[(size_t)n_pad + pt] = v4f{ao[0][1], ao[1][1], ao[2][1], ao[3][1]};
+      if (g == 0) {               // rows 0..3 of the tile live in the g == 0 lanes: [output][channel] of point n
+        float* __restrict__ dst = OP + (wave * 16 + n) * 8;
+        *reinterpret_cast<v4f*>(dst) = v4f{ao[0][0], ao[1][0], ao[2][0], ao[3][0]};
+        *reinterpret_cast<v4f*>(dst + 4) = v4f{ao[0][1], ao[1][1], ao[2][1], ao[3][1]};
       }
     }
-    lds_barrier();                // wave 3 is done with the last tile before the next group reuses it
+    lds_barrier();                // partials published; every wave is done with the last tile
+    if (wave == 3 && lane < 16 * NO) {          // lane = (output o, point n'): sum the four partials in wave order
+      const int o = lane >> 4, np = lane & 15;
+      v4f tot = *reinterpret_cast<const v4f*>(OP + (0 * 16 + np) * 8 + 4 * o);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) tot += *reinterpret_cast<const v4f*>(OP + (w * 16 + np) * 8 + 4 * o);
+      Ov[(size_t)o * n_pad + base + grp * 16 + np] = tot;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
