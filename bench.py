@@ -263,6 +263,7 @@ def main():
                                    "MLP, N_u=100, N_f=%d per GPU (LHS, seed 1234), %d Adam + %d L-BFGS "
                                    "iterations, canonical glorot init" % (args.nf_per_gpu, k_adam, k_lbfgs),
                        "n_f_total": n_f_total, "n_u": 100, "parallelism": "dp%d" % world, "allreduce": comm_mode,
+                       "allreduce_probe_us": getattr(eng, "comm_probe_us", None),
                        "replicas_identical": replicas_identical,
                        "kernel_path": eng.kernel_path(), "lbfgs_done_code": int(done) if k_lbfgs else None},
             "float64_leg": f64_leg,

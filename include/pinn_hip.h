@@ -149,6 +149,10 @@ int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank);
 int pinn_comm_xgmi_export(pinn_ctx* c, int n_ranks, int rank, char* handle64);
 int pinn_comm_xgmi_attach(pinn_ctx* c, const char* handles, int n_handles, int* mapped_ok);
 int pinn_comm_xgmi_selftest(pinn_ctx* c, int* ok);
+/* Wall time per exchange of the [P+4] vector with the given implementation (1 RCCL: k_reduce_rows + ncclAllReduce,
+ * 2 mailboxes: k_reduce_xgmi), measured on this node: what init_engine_comm uses to pick the faster one.
+ * Collective: every rank must call it with the same mode and iteration count. */
+int pinn_comm_benchmark(pinn_ctx* c, int mode, int iters, double* us_per_iter);
 int pinn_comm_set_mode(pinn_ctx* c, int mode);
 int pinn_comm_get_mode(pinn_ctx* c, int* mode);
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/pinn_hip.h"
@@ -1295,6 +1296,45 @@ int pinn_comm_xgmi_selftest(pinn_ctx* c, int* ok) {
   REQUIRE(c->xg.attached, "pinn_comm_xgmi_attach first");
   HIPCHK(hipSetDevice(c->device));
   return xg_self_test(c, ok);
+}
+
+int pinn_comm_benchmark(pinn_ctx* c, int mode, int iters, double* us_per_iter) {
+  REQUIRE(c && us_per_iter && iters >= 1 && (mode == 1 || mode == 2), "bad arguments");
+  if (mode == 1) REQUIRE(c->comm, "no RCCL communicator");
+  if (mode == 2) REQUIRE(c->xg.attached, "mailboxes are not attached");
+  HIPCHK(hipSetDevice(c->device));
+  const int R = c->R;
+  double *vec = nullptr, *out = nullptr;
+  if (dev_alloc(&vec, (size_t)R * 8) || dev_alloc(&out, (size_t)R * 8)) return PINN_EHIP;
+  HIPCHK(hipMemsetAsync(vec, 0, (size_t)R * 8, c->stream));
+  const dim3 grid((R + RED_COLS - 1) / RED_COLS), block(RED_THREADS);
+  auto once = [&]() -> int {
+    if (mode == 1) {
+      hipLaunchKernelGGL((k_reduce_rows<double>), grid, block, 0, c->stream, (const double*)vec, 1, R, out);
+      NCCLCHK(ncclAllReduce(out, out, (size_t)R, ncclDouble, ncclSum, c->comm, c->stream));
+    } else {
+      if (++c->xg.seq == 0) c->xg.seq = 2;
+      hipLaunchKernelGGL((k_reduce_xgmi<double, false>), grid, block, 0, c->stream, (const double*)vec, 1, R, out,
+                         c->xg.peers, c->xg.seq, XG_TEST_TIMEOUT_TICKS, c->xg.err, 0, (double*)nullptr,
+                         (double*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 0.0, 0.0, 0.0, (double*)nullptr,
+                         c->nd, (float*)nullptr);
+    }
+    return 0;
+  };
+  for (int i = 0; i < 10; ++i) if (int rc = once()) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < iters; ++i) if (int rc = once()) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *us_per_iter = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters;
+  HIPCHK(hipGetLastError());
+  (void)hipFree(vec); (void)hipFree(out);
+  if (mode == 2) {
+    int e = 0;
+    HIPCHK(hipMemcpy(&e, c->xg.err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) { HIPCHK(hipMemset(c->xg.err, 0, sizeof(int))); return fail(PINN_ECOMM, "mailbox exchange timed out in the probe"); }
+  }
+  return 0;
 }
 
 int pinn_comm_set_mode(pinn_ctx* c, int mode) {

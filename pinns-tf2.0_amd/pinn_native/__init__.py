@@ -100,6 +100,7 @@ _SIGNATURES = {
     "pinn_comm_xgmi_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "pinn_comm_xgmi_attach": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, _c_int_p]),
     "pinn_comm_xgmi_selftest": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
+    "pinn_comm_benchmark": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_double_p]),
     "pinn_comm_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_comm_get_mode": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
     "pinn_lhs_collocation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
@@ -374,6 +375,12 @@ class Engine(object):
         ok = ctypes.c_int(0)
         self._check(self._lib.pinn_comm_xgmi_selftest(self._h, ctypes.byref(ok)))
         return bool(ok.value)
+
+    def comm_benchmark(self, mode, iters=200):
+        us = ctypes.c_double(0.0)
+        self._check(self._lib.pinn_comm_benchmark(self._h, {"rccl": 1, "mailbox": 2}.get(mode, mode), int(iters),
+                                                  ctypes.byref(us)))
+        return us.value
 
     def comm_set_mode(self, mode):
         self._check(self._lib.pinn_comm_set_mode(self._h, {"rccl": 1, "mailbox": 2}.get(mode, mode)))

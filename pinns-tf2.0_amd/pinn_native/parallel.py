@@ -53,6 +53,7 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
         engine.comm_init(box[0], world, rank)
     if mailbox is None:
         mailbox = policy != "rccl"
+    engine.comm_probe_us = None
     if not mailbox:
         return "rccl"
     try:
@@ -79,6 +80,22 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
         except PinnNativeError:
             ok = False
         mapped, verdicts = agree(ok)
+    engine.comm_probe_us = None
+    if mapped and rccl and policy == "auto":
+        # both implementations work here: keep the one that is faster ON THIS NODE (collective timing of the
+        # exchange alone; every rank takes the same decision from the gathered numbers)
+        try:
+            mine = (engine.comm_benchmark("rccl"), engine.comm_benchmark("mailbox"))
+        except PinnNativeError:
+            mine = None
+        probes = [None] * world
+        dist.all_gather_object(probes, mine)
+        if all(p is not None for p in probes):
+            t_rccl, t_box = max(p[0] for p in probes), max(p[1] for p in probes)
+            engine.comm_probe_us = {"rccl": t_rccl, "mailbox": t_box}
+            mapped = t_box <= t_rccl
+        else:
+            mapped = False
     if mapped:
         engine.comm_set_mode("mailbox")
         return "mailbox"

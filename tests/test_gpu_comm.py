@@ -73,3 +73,33 @@ def test_mailbox_allreduce_between_processes(world):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(here, "helpers", "mailbox_ranks.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "MAILBOX_OK world=%d" % world in res.stdout, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def test_auto_policy_probes_both_implementations(burgers_sets, monkeypatch):
+    """init_engine_comm, policy auto, on a one-rank world: RCCL communicator + mailboxes, self-test, then the exchange
+    of both implementations is timed and the faster one kept; either way the evaluation is unchanged."""
+    from pinn_native.parallel import init_engine_comm
+
+    class OneRankWorld(object):          # the three torch.distributed calls the helper uses, for world size 1
+        @staticmethod
+        def broadcast_object_list(box, src=0):
+            pass
+
+        @staticmethod
+        def all_gather_object(out, obj):
+            out[0] = obj
+
+    monkeypatch.delenv("PINN_COMM", raising=False)
+    eng, X_f, X_u, u = _engine(burgers_sets, "f32")
+    eng.set_collocation(X_f); eng.set_data(X_u, u)
+    g = np.load(golden("burgers_eval_small.npz"))
+    eng.set_weights(g["w0"])
+    ref = eng.loss_grad()
+    mode = init_engine_comm(eng, OneRankWorld, 1, 0)
+    assert mode in ("rccl", "mailbox") and eng.comm_mode() == mode
+    probe = eng.comm_probe_us
+    assert probe and probe["rccl"] > 0 and probe["mailbox"] > 0
+    assert (mode == "mailbox") == (probe["mailbox"] <= probe["rccl"])
+    got = eng.loss_grad()
+    assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
+    eng.close()
