@@ -143,3 +143,24 @@ def test_wide_hidden_layers_f32():
     assert abs(loss - lo) <= 2e-5 * abs(lo) and rel(grad, go) <= 2e-4
     with pytest.raises(pinn_native.PinnNativeError, match="hidden width"):
         pinn_native.Engine(layers, [-1.0], [1.0], pde="burgers_disc", dtype="f64")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_many_groups(dtype):
+    """a few thousand points (hundreds of 16-point groups, two sets): more workgroups than compute units"""
+    from oracle import disc
+    rs = np.random.RandomState(11)
+    q, layers = 20, [1, 50, 50, 50, 21]
+    A, b, c = disc.gauss_legendre_butcher(q)
+    M = 0.05 * np.vstack([A, b[None, :]])
+    n0, n1 = 4100, 777
+    x0, x1 = rs.uniform(-1, 1, (n0, 1)), rs.uniform(-1, 1, (n1, 1))
+    sets = [(x0, -np.sin(np.pi * x0), M), (x1, 0.1 * rs.standard_normal((n1, 1)), -0.5 * M)]
+    w = 0.4 * rs.standard_normal(sum(a * b + b for a, b in zip(layers[:-1], layers[1:])))
+    eng = make_engine(layers, sets, dtype)
+    eng.set_weights(w)
+    loss, grad, terms = eng.loss_grad()
+    lo, go, ex = disc.disc_loss_grad(w, layers, [-1.0], [1.0], sets, nu=NU)
+    tl, tg = TOL[dtype]
+    assert abs(loss - lo) <= tl * abs(lo) and rel(grad, go) <= tg
+    assert abs(terms[0] - ex["sse"][0]) <= tl * abs(lo) and abs(terms[1] - ex["sse"][1]) <= tl * abs(lo)
