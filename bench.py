@@ -157,6 +157,14 @@ def main():
     # ---- warm-up (untimed): W optimiser iterations in the same 1:2 Adam:L-BFGS mix, so that every
     # kernel of the timed region has been loaded and every device buffer allocated beforehand
     if args.warmup > 0:
+        # a fresh box idles at 570 MHz: keep the GPU busy for ~0.3 s first so that the W warm-up steps and the timed
+        # region run at the sustained clock (extra untimed work only; the timed region is still exactly K steps)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 0.3:
+            eng.adam_run(200, want_losses=False)
+            eng.sync()
+        eng.set_weights(w0)
+        eng.adam_init(0.03, 0.9, 0.999, 1e-7)
         w_adam = max(args.warmup // 3, 1)
         w_lbfgs = max(args.warmup - w_adam, 2)
         eng.adam_run(w_adam, want_losses=False)
