@@ -168,7 +168,10 @@ int pinn_comm_get_mode(pinn_ctx* c, int* mode);
 int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);
 int pinn_sync(pinn_ctx* c);
-/* which kernel family serves the loss+grad evaluation: 0 generic, 1 fused width-20 */
+/* which kernel family serves the loss+grad evaluation: 0 generic (one lane per point), 1 fused width-20 (HBM stash),
+ * 2 fused 8x20 float32 (MFMA GEMVs, register stash), 3 wide MFMA sweeps (width 100, two outputs, float32),
+ * 4 shape-generic MFMA sweeps (any width <= 128 / 64 in float64, any depth), 5 / 6 = 4's forward / reverse half
+ * paired with the generic other half (tests).  The engine picks the fastest eligible family at pinn_create. */
 int pinn_set_kernel_path(pinn_ctx* c, int path);
 int pinn_get_kernel_path(pinn_ctx* c, int* path);
 /* Profiling build (-DPINN_STAMPS) only: one evaluation with a per-wave s_memtime timeline of the

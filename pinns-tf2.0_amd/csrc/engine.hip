@@ -21,6 +21,7 @@
 #include "kernels_optim.h"
 #include "kernels_disc.h"
 #include "kernels_sampling.h"
+#include "kernels_tile16.h"
 #include "kernels_xgmi.h"
 
 using namespace pinn;
@@ -180,6 +181,14 @@ static bool wide_ok(const pinn_ctx* c) {
          c->pde == PINN_PDE_SCHRODINGER;
 }
 
+// the shape-generic MFMA sweeps (kernels_tile16.h): any width up to 128 (64 in float64), any depth
+static bool tile16_ok(const pinn_ctx* c) {
+  return !is_disc(c) && c->nd.width <= (c->dtype == PINN_F64 ? 64 : 128) && c->nd.n_out <= 2;
+}
+static bool t16_fwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 5; }
+static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6; }
+static int t16_wgs(const pinn_ctx* c, int pts) { const int g = pts / 16, cap = 2 * c->n_cu; return g < cap ? g : cap; }
+
 template <typename T>
 static int dev_alloc(T** p, size_t bytes) {
   if (*p) (void)hipFree(*p);
@@ -275,7 +284,7 @@ static int ensure_sets(pinn_ctx* c) {
   const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
   c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (path 2)
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
-  const size_t rows = c->path == 3 ? (size_t)wide_wg : c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
+  const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
   const size_t need_S = c->path == 2 ? 16 : H * W * stash_pts * 4 * rs;
   const size_t need_Z = c->path == 2 ? 16 : W * (size_t)c->chunk * 4 * rs;
   const size_t need_part = rows * c->R * rs;
@@ -329,6 +338,46 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
   return 0;
 }
 
+// shape-generic MFMA sweeps for one chunk (kernels_tile16.h)
+template <typename real, int NT>
+static int t16_launch_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
+  static unsigned long long attr = 0;
+  const size_t lds = t16_fwd_lds<NT>(sizeof(real));
+  if (first_call_on_device(attr))
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_t16_fwd<real, NT>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd,
+                     (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, base, c->sd.n_pad, c->chunk,
+                     pts / 16, lbx, lbt, sx, st, (vec4<real>*)c->S, (vec4<real>*)c->O);
+  return 0;
+}
+template <typename real, int NT, int PDE, bool WLDS>
+static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
+  static unsigned long long attr = 0;
+  const size_t lds = t16_bwd_lds<NT>(sizeof(real), WLDS);
+  if (first_call_on_device(attr))
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_bwd<real, NT, PDE, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL((k_t16_bwd<real, NT, PDE, WLDS>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd, c->sd,
+                     (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, (const real*)c->tgt, base,
+                     c->sd.n_pad, c->chunk, pts / 16, lbx, lbt, sx, st, (real)c->nu, (const vec4<real>*)c->S,
+                     (const vec4<real>*)c->O, (real*)c->part, c->R, accumulate);
+  return 0;
+}
+template <typename real>
+static int t16_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
+  if constexpr (sizeof(real) == 4) {
+    if (c->nd.width > 64) return t16_launch_fwd<real, 8>(c, base, pts, lbx, lbt, sx, st);
+  }
+  return t16_launch_fwd<real, 4>(c, base, pts, lbx, lbt, sx, st);
+}
+template <typename real, int PDE>
+static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
+  if constexpr (sizeof(real) == 4) {
+    if (c->nd.width > 64) return t16_launch_bwd<real, 8, PDE, false>(c, base, pts, lbx, lbt, sx, st, accumulate);
+  }
+  return t16_launch_bwd<real, 4, PDE, true>(c, base, pts, lbx, lbt, sx, st, accumulate);
+}
+
 template <typename real, int PDE>
 static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   constexpr int JT = sizeof(real) == 4 ? 20 : 10;
@@ -357,6 +406,10 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
       const dim3 grid(pts / 64), block(64);
       bool fwd_done = false;
+      if (t16_fwd_on(c)) {
+        if (int rc = t16_fwd<real>(c, base, pts, lbx, lbt, sx, st)) return rc;
+        fwd_done = true;
+      }
       if constexpr (sizeof(real) == 4) {
         if (c->path == 3) {
           static unsigned long long attr = 0;
@@ -379,6 +432,10 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
                          (vec4<real>*)c->O);
       if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
       bool bwd_done = false;
+      if (t16_bwd_on(c)) {
+        if (int rc = t16_bwd<real, PDE>(c, base, pts, lbx, lbt, sx, st, ci > 0 ? 1 : 0)) return rc;
+        bwd_done = true;
+      }
       if constexpr (sizeof(real) == 4 && PDE == 2) {
         if (c->path == 3) {
           static unsigned long long attr = 0;
@@ -406,7 +463,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     }
   }
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
-  const int n_rows = c->path == 3 ? ((c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu)
+  const int n_rows = t16_bwd_on(c) ? t16_wgs(c, c->chunk)
+                   : c->path == 3 ? ((c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu)
                    : c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
   return launch_reduce<real>(c, n_rows, af);
 }
@@ -781,7 +839,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   }
   // default kernel family: 2 width-20 f32 (MFMA GEMVs, register stash), 1 width-20 HBM-stash,
   // 3 wide MFMA sweeps (width 100, 2 outputs), 0 generic
-  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : 0;
+  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : tile16_ok(c) ? 4 : 0;
   *out = c;
   return 0;
 }
@@ -1405,7 +1463,9 @@ int pinn_sync(pinn_ctx* c) {
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
-  REQUIRE(c && path >= 0 && path <= 3, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash) or 3 (wide MFMA sweeps)");
+  REQUIRE(c && path >= 0 && path <= 6, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
+          "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half)");
+  if (path >= 4) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128 (64 in float64)");
   if (path == 3) REQUIRE(wide_ok(c), "the wide path needs float32, hidden width 100 and two outputs");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");

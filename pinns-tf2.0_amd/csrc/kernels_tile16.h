@@ -1,0 +1,346 @@
+// kernels_tile16.h -- shape-generic MFMA sweeps for the continuous models: any uniform hidden width up to 128
+// (64 in float64), any depth, 1-2 outputs, all three residual kinds, float32 and float64 -- the fast path for every
+// network the width-20 / width-100 kernels do not serve (until now those shapes ran on the one-lane-per-point
+// VALU kernels of kernels_generic.h at ~1 TFLOP/s).
+//
+// Mapping (the same as kernels_wide.h, with runtime width/depth and a compile-time tile count NT = ceil(W/16)):
+//   workgroup = 4 waves = one group of 16 points at a time, persistent over groups;
+//   every layer is  Z[feature][point] = W^T[feature][k] . IN[k][point]  on v_mfma_{f32,f64}_16x16x4: the A operand
+//   is the weight tile (features on the M side), the B operand the exchange tile, so the accumulator register r of
+//   lane (n = point, g) is feature out_row(lane, r) of point n: the four Taylor channels of a (feature, point) sit
+//   in one lane (tanh chain lane-local) and stash / exchange-tile accesses run along the points (coalesced);
+//   exchange tiles are [feature][17] vec4 (value, d/dx, d/dt, d2/dx2): one LDS read serves the four channel MFMAs;
+//   weights of the layer in flight live in LDS, fetched one layer ahead through registers (as in kernels_disc.h);
+//   stash S and outputs O use the generic kernels' layout, so either half can be paired with k_forward/k_backward
+//   (which is how the tests pin each half);
+//   weight gradients: NT x NT tiles x 16 MFMAs per layer and group, *added* into the workgroup's own partial row
+//   (read-modify-write in L2/HBM: at most 2 P sizeof(real) bytes per group against 24 M_w x 16 FLOP, < 10 % of the
+//   time at every shape) -- no register-resident accumulators, so the kernel has room for float64 and for two
+//   workgroups per CU.
+// Math: SURVEY.md Appendix A (channels_of / preact_adjoint / point_seeds of kernels_generic.h).
+#pragma once
+#include "kernels_disc.h"
+
+namespace pinn {
+
+template <int NT> struct T16Geo {
+  static constexpr int WP = 16 * NT;
+  static constexpr int PD = 17;                // exchange tile row pitch in vec4 (16 points + 1 pad)
+  static constexpr int TILE = WP * PD;         // vec4 per exchange tile
+  static constexpr int WLD = WP + 16;          // weights [k][j] read as A[m = j][4s+g = k]: rows 4s+g, cols m
+  static constexpr int TLD = WP + 4;           // weights [k][j] read as A[m = k][4s+g = j]
+  static constexpr int NPRE = WP * WP / 256;
+};
+template <int NT> inline size_t t16_fwd_lds(size_t rs) {
+  return (size_t)(2 * T16Geo<NT>::TILE * 4 + T16Geo<NT>::WP * T16Geo<NT>::WLD + 8 * 2 * 16 * 4) * rs;
+}
+template <int NT> inline size_t t16_bwd_lds(size_t rs, bool wlds) {
+  return (size_t)(3 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::TLD : 0) + 2 * 16 * 4 + 32) * rs;
+}
+
+template <typename real>
+__device__ __forceinline__ real sum16(real v) {        // sum over the 16 lanes of a DPP row; every lane gets it
+  v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward sweep over points [base, base + 16 n_groups): fills S and O exactly as k_forward does
+// ---------------------------------------------------------------------------------------------------------
+template <typename real, int NT>
+__global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restrict__ th,
+                                                 const real* __restrict__ xs, const real* __restrict__ ts, int base,
+                                                 int n_pad, int s_pad, int n_groups, real lbx, real lbt, real sx,
+                                                 real st, vec4<real>* __restrict__ S, vec4<real>* __restrict__ O) {
+  using TR = FusedTraits<real>;
+  using acc_t = typename TR::acc_t;
+  using GEO = T16Geo<NT>;
+  using V4 = vec4<real>;
+  constexpr int WP = GEO::WP, PD = GEO::PD, WLD = GEO::WLD;
+  extern __shared__ __attribute__((aligned(16))) char t16_smem[];
+  V4* const T0 = reinterpret_cast<V4*>(t16_smem);
+  V4* const T1 = T0 + GEO::TILE;
+  real* const wb = reinterpret_cast<real*>(T1 + GEO::TILE);      // [WP][WLD]
+  real* const red = wb + WP * WLD;                                // [8][2][16][4] output-layer partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
+  const int m = lane & 15, g = lane >> 4;
+  const int ksteps = (W + 3) / 4;
+  const int pe = tid & 15;                                        // the point of this thread's elementwise items
+
+  real pre[GEO::NPRE];
+  if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[1], W, W, W, tid);
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int lp0 = grp * 16;
+    {  // dense 0: items (feature j, point pe), point fastest
+      const real x = xs[base + lp0 + pe], t = ts[base + lp0 + pe];
+      const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
+      for (int j = tid >> 4; j < WP; j += 16) {
+        V4 s{0, 0, 0, 0}, c{0, 0, 0, 0};
+        if (j < W) {
+          const real w0 = th[nd.off_w[0] + j], w1 = th[nd.off_w[0] + W + j], b0 = th[nd.off_b[0] + j];
+          s = V4{tanh_r(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
+          S[(size_t)j * s_pad + lp0 + pe] = s;
+          real d1, d2;
+          c = channels_of(s, d1, d2);
+        }
+        T0[j * PD + pe] = c;
+      }
+    }
+    V4* Tin = T0;
+    V4* Tout = T1;
+    for (int l = 1; l < H; ++l) {
+      __syncthreads();                        // Tin published; nobody reads wb any more
+      wt_store<real, NT, WP>(pre, wb, WLD, tid);
+      __syncthreads();
+      {                                       // next matrix on its way: W_{l+1}, or W_1 for the next group
+        const int ln = l + 1 < H ? l + 1 : 1;
+        wt_load<real, NT, WP>(pre, th + nd.off_w[ln], W, W, W, tid);
+      }
+      const real* __restrict__ bl = th + nd.off_b[l];
+      for (int ct = wave; ct < NT; ct += 4) {
+        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const int k = 4 * ks + g;
+          const real a = wb[k * WLD + 16 * ct + m];               // A[m = feature 16ct+m][k]
+          const V4 b = Tin[k * PD + m];                           // B[k][n = point m]
+          a0 = TR::mfma(a, b.x, a0);
+          a1 = TR::mfma(a, b.y, a1);
+          a2 = TR::mfma(a, b.z, a2);
+          a3 = TR::mfma(a, b.w, a3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * ct + TR::out_row(lane, r);           // feature; the point is m
+          V4 c{0, 0, 0, 0};
+          if (j < W) {
+            const V4 s{tanh_r(a0[r] + bl[j]), a1[r], a2[r], a3[r]};
+            S[((size_t)l * W + j) * s_pad + lp0 + m] = s;
+            real d1, d2;
+            c = channels_of(s, d1, d2);
+          }
+          Tout[j * PD + m] = c;
+        }
+      }
+      V4* tmp = Tin; Tin = Tout; Tout = tmp;
+    }
+    __syncthreads();
+    {  // linear output layer: thread = (k-slice ks8, output o, point pe); 8 slices summed through LDS
+      const int o = (tid >> 4) & 1, ks8 = tid >> 5;
+      V4 acc{0, 0, 0, 0};
+      if (o < NO)
+        for (int k = ks8; k < W; k += 8) {
+          const real w = th[nd.off_w[H] + k * NO + o];
+          const V4 b = Tin[k * PD + pe];
+          acc.x += b.x * w; acc.y += b.y * w; acc.z += b.z * w; acc.w += b.w * w;
+        }
+      reinterpret_cast<V4*>(red)[(ks8 * 2 + o) * 16 + pe] = acc;
+      __syncthreads();
+      if (ks8 == 0 && o < NO) {
+        V4 tot = reinterpret_cast<V4*>(red)[(0 * 2 + o) * 16 + pe];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) {
+          const V4 v = reinterpret_cast<V4*>(red)[(q * 2 + o) * 16 + pe];
+          tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        }
+        tot.x += th[nd.off_b[H] + o];
+        O[(size_t)o * n_pad + base + lp0 + pe] = tot;
+      }
+    }
+    __syncthreads();                          // the next group's dense 0 overwrites T0
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reverse sweep over points [base, base + 16 n_groups), consuming S and O: seeds, adjoints through every layer,
+// all weight gradients added into one partial row per workgroup (zeroed here unless `accumulate`).
+// WLDS: the layer's weight matrix is staged in LDS for the adjoint GEMM (else read from global / L2).
+// ---------------------------------------------------------------------------------------------------------
+template <typename real, int NT, int PDE, bool WLDS>
+__global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const real* __restrict__ th,
+                                                 const real* __restrict__ xs, const real* __restrict__ ts,
+                                                 const real* __restrict__ tgt, int base, int n_pad, int s_pad,
+                                                 int n_groups, real lbx, real lbt, real sx, real st, real nu,
+                                                 const vec4<real>* __restrict__ S, const vec4<real>* __restrict__ O,
+                                                 real* __restrict__ part, int R, int accumulate) {
+  using TR = FusedTraits<real>;
+  using acc_t = typename TR::acc_t;
+  using GEO = T16Geo<NT>;
+  using V4 = vec4<real>;
+  constexpr int WP = GEO::WP, PD = GEO::PD, TLD = GEO::TLD;
+  extern __shared__ __attribute__((aligned(16))) char t16_smem[];
+  V4* const TI = reinterpret_cast<V4*>(t16_smem);                 // inputs of the layer being reversed
+  V4* const BA = TI + GEO::TILE;                                  // pre-activation adjoints, ping
+  V4* const BB = BA + GEO::TILE;                                  // ... pong
+  real* const wt = reinterpret_cast<real*>(BB + GEO::TILE);       // [WP][TLD] (WLDS only)
+  V4* const seeds = reinterpret_cast<V4*>(wt + (WLDS ? WP * TLD : 0));   // [2][16]
+  real* const hxy = reinterpret_cast<real*>(seeds + 32);          // [2][16] normalised inputs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
+  const int m = lane & 15, g = lane >> 4, pe = tid & 15;
+  const int ksteps = (W + 3) / 4;
+  real* __restrict__ row = part + (size_t)blockIdx.x * R;
+  real c1 = real(1), c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp_r(th[nd.n_net + 1]); }
+
+  if (!accumulate) {
+    for (int i = tid; i < R; i += 256) row[i] = real(0);
+    __syncthreads();                          // (global stores of one workgroup, read back by the same workgroup)
+  }
+  real l_acc[3] = {0, 0, 0}, dl_acc[2] = {0, 0}, gb_acc[2] = {0, 0};   // threads 0..15: one point each
+
+  real pre[GEO::NPRE];                        // (dead when !WLDS)
+  if constexpr (WLDS) { if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[H - 1], W, W, W, tid); }
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int lp0 = grp * 16;
+    if (tid < 16) {
+      const int pt = base + lp0 + tid;
+      V4 sb[2];
+      real lt[3], dl[2];
+      point_seeds<real, PDE>(sd, pt, n_pad, O, tgt, c1, c2, sb, lt, dl);
+      seeds[tid] = sb[0]; seeds[16 + tid] = sb[1];
+      l_acc[0] += lt[0]; l_acc[1] += lt[1]; l_acc[2] += lt[2];
+      dl_acc[0] += dl[0]; dl_acc[1] += dl[1];
+      gb_acc[0] += sb[0].x; gb_acc[1] += sb[1].x;
+      hxy[tid] = sx * (xs[pt] - lbx) - real(1);
+      hxy[16 + tid] = st * (ts[pt] - lbt) - real(1);
+    }
+    __syncthreads();
+    V4* Bcur = BA;
+    V4* Bnxt = BB;
+    {  // dense H (linear): z_bar = seeds.  Items (feature j, point pe): adjoint of layer H-1's pre-activations,
+       // gradient of the output weights (sum over the 16 points = the 16 lanes of a DPP row), inputs of layer H-1
+      const V4 s0 = seeds[pe], s1 = seeds[16 + pe];
+      for (int j = tid >> 4; j < WP; j += 16) {
+        V4 zb{0, 0, 0, 0};
+        real gw0 = 0, gw1 = 0;
+        if (j < W) {
+          const V4 s = S[((size_t)(H - 1) * W + j) * s_pad + lp0 + pe];
+          real d1, d2;
+          const V4 in = channels_of(s, d1, d2);
+          const real w0 = th[nd.off_w[H] + j * NO], w1 = NO > 1 ? th[nd.off_w[H] + j * NO + 1] : real(0);
+          V4 ob{s0.x * w0 + s1.x * w1, s0.y * w0 + s1.y * w1, s0.z * w0 + s1.z * w1, s0.w * w0 + s1.w * w1};
+          zb = preact_adjoint(s, ob);
+          gw0 = dot4(in, s0);
+          gw1 = dot4(in, s1);
+        }
+        Bcur[j * PD + pe] = zb;
+        gw0 = sum16(gw0);
+        gw1 = sum16(gw1);
+        if (pe == 0 && j < W) {
+          row[nd.off_w[H] + j * NO] += gw0;
+          if (NO > 1) row[nd.off_w[H] + j * NO + 1] += gw1;
+        }
+        if (H > 1) {
+          V4 c{0, 0, 0, 0};
+          if (j < W) {
+            real d1, d2;
+            c = channels_of(S[((size_t)(H - 2) * W + j) * s_pad + lp0 + pe], d1, d2);
+          }
+          TI[j * PD + pe] = c;
+        }
+      }
+    }
+    for (int d = H - 1; d >= 1; --d) {
+      if constexpr (WLDS) wt_store<real, NT, WP>(pre, wt, TLD, tid);
+      __syncthreads();                        // Bcur (z_bar of layer d), TI (inputs of layer d), weights published
+      if constexpr (WLDS) {                   // next matrix: W_{d-1}, or W_{H-1} for the next group
+        const int dn = d >= 2 ? d - 1 : H - 1;
+        wt_load<real, NT, WP>(pre, th + nd.off_w[dn], W, W, W, tid);
+      }
+      // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j
+      for (int tau = wave; tau < NT * NT; tau += 4) {
+        const int rt = tau / NT, ct = tau - rt * NT;
+        if (16 * rt >= W || 16 * ct >= W) continue;               // wave-uniform: tile entirely in the padding
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
+          acc = TR::mfma(A.x, B.x, acc);
+          acc = TR::mfma(A.y, B.y, acc);
+          acc = TR::mfma(A.z, B.z, acc);
+          acc = TR::mfma(A.w, B.w, acc);
+        }
+        const int j = 16 * ct + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rt + TR::out_row(lane, r);
+          if (k < W && j < W) row[nd.off_w[d] + k * W + j] += acc[r];
+        }
+      }
+      if (tid < W) {                          // bias gradient of layer d
+        real sb_ = 0;
+        for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
+        row[nd.off_b[d] + tid] += sb_;
+      }
+      // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
+      const real* __restrict__ Wd = th + nd.off_w[d];
+      for (int kt = wave; kt < NT; kt += 4) {
+        V4 sk[4];                             // stash of layer d-1 for this lane's four features (point m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kt + TR::out_row(lane, r);
+          sk[r] = k < W ? S[((size_t)(d - 1) * W + k) * s_pad + lp0 + m] : V4{0, 0, 0, 0};
+        }
+        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int ks = 0; ks < ksteps; ++ks) {
+          const int jj = 4 * ks + g, k = 16 * kt + m;
+          const real a = WLDS ? wt[k * TLD + jj] : ((k < W && jj < W) ? Wd[k * W + jj] : real(0));
+          const V4 b = Bcur[jj * PD + m];
+          a0 = TR::mfma(a, b.x, a0);
+          a1 = TR::mfma(a, b.y, a1);
+          a2 = TR::mfma(a, b.z, a2);
+          a3 = TR::mfma(a, b.w, a3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * kt + TR::out_row(lane, r);
+          Bnxt[k * PD + m] = k < W ? preact_adjoint(sk[r], V4{a0[r], a1[r], a2[r], a3[r]}) : V4{0, 0, 0, 0};
+        }
+      }
+      __syncthreads();                        // every wave is done reading TI before it is refilled
+      if (d >= 2)                             // inputs of layer d-1 = output channels of layer d-2
+        for (int j = tid >> 4; j < WP; j += 16) {
+          V4 c{0, 0, 0, 0};
+          if (j < W) {
+            real d1, d2;
+            c = channels_of(S[((size_t)(d - 2) * W + j) * s_pad + lp0 + pe], d1, d2);
+          }
+          TI[j * PD + pe] = c;
+        }
+      V4* tmp = Bcur; Bcur = Bnxt; Bnxt = tmp;
+    }
+    __syncthreads();                          // z_bar of dense 0 published (also covers H == 1)
+    if (tid < W) {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
+      real gx = 0, gt = 0, gb = 0;
+      for (int p = 0; p < 16; ++p) {
+        const V4 zb = Bcur[tid * PD + p];
+        gx += hxy[p] * zb.x + sx * zb.y;
+        gt += hxy[16 + p] * zb.x + st * zb.z;
+        gb += zb.x;
+      }
+      row[nd.off_w[0] + tid] += gx;
+      row[nd.off_w[0] + W + tid] += gt;
+      row[nd.off_b[0] + tid] += gb;
+    }
+    __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group
+  }
+  if (tid < 16) {   // loss parts, lambda gradients, output biases: sums over this workgroup's points
+#pragma unroll
+    for (int k = 0; k < 3; ++k) l_acc[k] = sum16(l_acc[k]);
+    dl_acc[0] = sum16(dl_acc[0]); dl_acc[1] = sum16(dl_acc[1]);
+    gb_acc[0] = sum16(gb_acc[0]); gb_acc[1] = sum16(gb_acc[1]);
+    if (tid == 0) {
+      row[nd.n_theta + 0] += l_acc[0]; row[nd.n_theta + 1] += l_acc[1]; row[nd.n_theta + 2] += l_acc[2];
+      row[nd.off_b[H]] += gb_acc[0];
+      if (NO > 1) row[nd.off_b[H] + 1] += gb_acc[1];
+      if (PDE == 1) { row[nd.n_net] += dl_acc[0]; row[nd.n_net + 1] += dl_acc[1]; }
+    }
+  }
+}
+
+}  // namespace pinn

@@ -1,7 +1,8 @@
 """GPU: randomized shape sweep of the continuous models through the C ABI against the oracle -- widths 1..128,
 2..12 dense layers, ragged point counts, all three residual kinds, f64 (1e-10) and f32 (5e-5): every kernel family
-the engine can choose for a shape (generic, HBM-stash width-20, register-stash 8x20, wide MFMA) is hit by some
-case, and for shapes with several eligible families all of them are compared."""
+the engine can choose for a shape (generic, HBM-stash width-20, register-stash 8x20, wide MFMA, shape-generic MFMA
+tile16 -- also each of its halves paired with the generic other half, paths 5 and 6) is hit by some case, and for
+shapes with several eligible families all of them are compared."""
 import numpy as np
 import pytest
 
@@ -60,7 +61,7 @@ def test_random_shapes_against_oracle(pde_kind, W, H, n_f, n_u, seed, dtype):
     tl, tg = (1e-11, 1e-10) if dtype == "f64" else (2e-5, 5e-5)
     default = eng.kernel_path()
     tried = 0
-    for path in (default, 0, 1, 2, 3):
+    for path in (default, 0, 1, 2, 3, 4, 5, 6):
         if tried and path == default:
             continue
         try:
