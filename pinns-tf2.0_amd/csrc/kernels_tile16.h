@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
       }
       const real* __restrict__ bl = th + nd.off_b[l];
       for (int ct = wave; ct < NT; ct += 4) {
+        real bj[4];                                               // biases of this lane's four features (in flight
+#pragma unroll                                                    //  under the MFMAs)
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * ct + TR::out_row(lane, r);
+          bj[r] = j < W ? bl[j] : real(0);
+        }
         acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
 #pragma unroll 4
         for (int ks = 0; ks < ksteps; ++ks) {
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
           const int j = 16 * ct + TR::out_row(lane, r);           // feature; the point is m
           V4 c{0, 0, 0, 0};
           if (j < W) {
-            const V4 s{tanh_r(a0[r] + bl[j]), a1[r], a2[r], a3[r]};
+            const V4 s{tanh_r(a0[r] + bj[r]), a1[r], a2[r], a3[r]};
             S[((size_t)l * W + j) * s_pad + lp0 + m] = s;
             real d1, d2;
             c = channels_of(s, d1, d2);
@@ -255,6 +261,13 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
       for (int tau = wave; tau < NT * NT; tau += 4) {
         const int rt = tau / NT, ct = tau - rt * NT;
         if (16 * rt >= W || 16 * ct >= W) continue;               // wave-uniform: tile entirely in the padding
+        const int j = 16 * ct + m;
+        real old[4];                                              // the row entries to update: fetched under the MFMAs
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rt + TR::out_row(lane, r);
+          old[r] = (k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
+        }
         acc_t acc = {0, 0, 0, 0};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -264,11 +277,10 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
           acc = TR::mfma(A.z, B.z, acc);
           acc = TR::mfma(A.w, B.w, acc);
         }
-        const int j = 16 * ct + m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * rt + TR::out_row(lane, r);
-          if (k < W && j < W) row[nd.off_w[d] + k * W + j] += acc[r];
+          if (k < W && j < W) row[nd.off_w[d] + k * W + j] = old[r] + acc[r];
         }
       }
       if (tid < W) {                          // bias gradient of layer d
