@@ -182,9 +182,7 @@ static bool wide_ok(const pinn_ctx* c) {
 }
 
 // the shape-generic MFMA sweeps (kernels_tile16.h): any width up to 128 (64 in float64), any depth
-static bool tile16_ok(const pinn_ctx* c) {
-  return !is_disc(c) && c->nd.width <= (c->dtype == PINN_F64 ? 64 : 128) && c->nd.n_out <= 2;
-}
+static bool tile16_ok(const pinn_ctx* c) { return !is_disc(c) && c->nd.width <= 128 && c->nd.n_out <= 2; }
 static bool t16_fwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 5; }
 static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6; }
 static int t16_wgs(const pinn_ctx* c, int pts) { const int g = pts / 16, cap = 2 * c->n_cu; return g < cap ? g : cap; }
@@ -339,13 +337,14 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
 }
 
 // shape-generic MFMA sweeps for one chunk (kernels_tile16.h)
-template <typename real, int NT>
+template <typename real, int NT, bool WLDS>
 static int t16_launch_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
   static unsigned long long attr = 0;
-  const size_t lds = t16_fwd_lds<NT>(sizeof(real));
+  const size_t lds = t16_fwd_lds<NT>(sizeof(real), WLDS);
   if (first_call_on_device(attr))
-    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((k_t16_fwd<real, NT>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd,
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL((k_t16_fwd<real, NT, WLDS>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd,
                      (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, base, c->sd.n_pad, c->chunk,
                      pts / 16, lbx, lbt, sx, st, (vec4<real>*)c->S, (vec4<real>*)c->O);
   return 0;
@@ -365,16 +364,14 @@ static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, re
 }
 template <typename real>
 static int t16_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
-  if constexpr (sizeof(real) == 4) {
-    if (c->nd.width > 64) return t16_launch_fwd<real, 8>(c, base, pts, lbx, lbt, sx, st);
-  }
-  return t16_launch_fwd<real, 4>(c, base, pts, lbx, lbt, sx, st);
+  // widths up to 64: four feature tiles; up to 128: eight (in float64 the weights then stay in L2: LDS is full)
+  if (c->nd.width > 64) return t16_launch_fwd<real, 8, sizeof(real) == 4>(c, base, pts, lbx, lbt, sx, st);
+  return t16_launch_fwd<real, 4, true>(c, base, pts, lbx, lbt, sx, st);
 }
 template <typename real, int PDE>
 static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
-  if constexpr (sizeof(real) == 4) {
-    if (c->nd.width > 64) return t16_launch_bwd<real, 8, PDE, false>(c, base, pts, lbx, lbt, sx, st, accumulate);
-  }
+  if (c->nd.width > 64)
+    return t16_launch_bwd<real, 8, PDE, sizeof(real) == 4>(c, base, pts, lbx, lbt, sx, st, accumulate);
   return t16_launch_bwd<real, 4, PDE, true>(c, base, pts, lbx, lbt, sx, st, accumulate);
 }
 
@@ -1465,7 +1462,7 @@ int pinn_sync(pinn_ctx* c) {
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
   REQUIRE(c && path >= 0 && path <= 6, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
           "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half)");
-  if (path >= 4) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128 (64 in float64)");
+  if (path >= 4) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
   if (path == 3) REQUIRE(wide_ok(c), "the wide path needs float32, hidden width 100 and two outputs");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");

@@ -31,11 +31,11 @@ template <int NT> struct T16Geo {
   static constexpr int TLD = WP + 4;           // weights [k][j] read as A[m = k][4s+g = j]
   static constexpr int NPRE = WP * WP / 256;
 };
-template <int NT> inline size_t t16_fwd_lds(size_t rs) {
-  return (size_t)(2 * T16Geo<NT>::TILE * 4 + T16Geo<NT>::WP * T16Geo<NT>::WLD + 8 * 2 * 16 * 4) * rs;
+template <int NT> inline size_t t16_fwd_lds(size_t rs, bool wlds) {
+  return (size_t)(2 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::WLD : 0) + 8 * 2 * 16 * 4) * rs;
 }
 template <int NT> inline size_t t16_bwd_lds(size_t rs, bool wlds) {
-  return (size_t)(3 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::TLD : 0) + 2 * 16 * 4 + 32) * rs;
+  return (size_t)(2 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::TLD : 0) + 2 * 16 * 4 + 32) * rs;
 }
 
 template <typename real>
@@ -47,7 +47,7 @@ __device__ __forceinline__ real sum16(real v) {        // sum over the 16 lanes 
 // ---------------------------------------------------------------------------------------------------------
 // forward sweep over points [base, base + 16 n_groups): fills S and O exactly as k_forward does
 // ---------------------------------------------------------------------------------------------------------
-template <typename real, int NT>
+template <typename real, int NT, bool WLDS>
 __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restrict__ th,
                                                  const real* __restrict__ xs, const real* __restrict__ ts, int base,
                                                  int n_pad, int s_pad, int n_groups, real lbx, real lbt, real sx,
@@ -60,16 +60,16 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
   extern __shared__ __attribute__((aligned(16))) char t16_smem[];
   V4* const T0 = reinterpret_cast<V4*>(t16_smem);
   V4* const T1 = T0 + GEO::TILE;
-  real* const wb = reinterpret_cast<real*>(T1 + GEO::TILE);      // [WP][WLD]
-  real* const red = wb + WP * WLD;                                // [8][2][16][4] output-layer partials
+  real* const wb = reinterpret_cast<real*>(T1 + GEO::TILE);      // [WP][WLD] (WLDS only; else weights come from L2)
+  real* const red = wb + (WLDS ? WP * WLD : 0);                   // [8][2][16][4] output-layer partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
   const int m = lane & 15, g = lane >> 4;
   const int ksteps = (W + 3) / 4;
   const int pe = tid & 15;                                        // the point of this thread's elementwise items
 
-  real pre[GEO::NPRE];
-  if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[1], W, W, W, tid);
+  real pre[GEO::NPRE];                        // (dead when !WLDS)
+  if constexpr (WLDS) { if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[1], W, W, W, tid); }
 
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int lp0 = grp * 16;
@@ -92,13 +92,14 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
     V4* Tout = T1;
     for (int l = 1; l < H; ++l) {
       __syncthreads();                        // Tin published; nobody reads wb any more
-      wt_store<real, NT, WP>(pre, wb, WLD, tid);
-      __syncthreads();
-      {                                       // next matrix on its way: W_{l+1}, or W_1 for the next group
-        const int ln = l + 1 < H ? l + 1 : 1;
+      if constexpr (WLDS) {
+        wt_store<real, NT, WP>(pre, wb, WLD, tid);
+        __syncthreads();
+        const int ln = l + 1 < H ? l + 1 : 1;  // next matrix on its way: W_{l+1}, or W_1 for the next group
         wt_load<real, NT, WP>(pre, th + nd.off_w[ln], W, W, W, tid);
       }
       const real* __restrict__ bl = th + nd.off_b[l];
+      const real* __restrict__ Wl = th + nd.off_w[l];
       for (int ct = wave; ct < NT; ct += 4) {
         real bj[4];                                               // biases of this lane's four features (in flight
 #pragma unroll                                                    //  under the MFMAs)
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
 #pragma unroll 4
         for (int ks = 0; ks < ksteps; ++ks) {
           const int k = 4 * ks + g;
-          const real a = wb[k * WLD + 16 * ct + m];               // A[m = feature 16ct+m][k]
+          const int ja = 16 * ct + m;                             // A[m = feature 16ct+m][k]
+          const real a = WLDS ? wb[k * WLD + ja] : ((k < W && ja < W) ? Wl[k * W + ja] : real(0));
           const V4 b = Tin[k * PD + m];                           // B[k][n = point m]
           a0 = TR::mfma(a, b.x, a0);
           a1 = TR::mfma(a, b.y, a1);
@@ -177,10 +179,12 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
   using V4 = vec4<real>;
   constexpr int WP = GEO::WP, PD = GEO::PD, TLD = GEO::TLD;
   extern __shared__ __attribute__((aligned(16))) char t16_smem[];
-  V4* const TI = reinterpret_cast<V4*>(t16_smem);                 // inputs of the layer being reversed
-  V4* const BA = TI + GEO::TILE;                                  // pre-activation adjoints, ping
-  V4* const BB = BA + GEO::TILE;                                  // ... pong
-  real* const wt = reinterpret_cast<real*>(BB + GEO::TILE);       // [WP][TLD] (WLDS only)
+  // two exchange tiles that swap roles every layer: X = inputs of the layer being reversed (A operand of dW), then
+  // overwritten by the adjoint of the layer below; Y = adjoint of this layer's pre-activations, then refilled with
+  // the inputs of the layer below
+  V4* const TA = reinterpret_cast<V4*>(t16_smem);
+  V4* const TB = TA + GEO::TILE;
+  real* const wt = reinterpret_cast<real*>(TB + GEO::TILE);       // [WP][TLD] (WLDS only)
   V4* const seeds = reinterpret_cast<V4*>(wt + (WLDS ? WP * TLD : 0));   // [2][16]
   real* const hxy = reinterpret_cast<real*>(seeds + 32);          // [2][16] normalised inputs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -215,8 +219,8 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
       hxy[16 + tid] = st * (ts[pt] - lbt) - real(1);
     }
     __syncthreads();
-    V4* Bcur = BA;
-    V4* Bnxt = BB;
+    V4* TI = TA;                              // inputs of the layer being reversed
+    V4* Bcur = TB;                            // adjoint of its pre-activations
     {  // dense H (linear): z_bar = seeds.  Items (feature j, point pe): adjoint of layer H-1's pre-activations,
        // gradient of the output weights (sum over the 16 points = the 16 lanes of a DPP row), inputs of layer H-1
       const V4 s0 = seeds[pe], s1 = seeds[16 + pe];
@@ -288,7 +292,9 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
         for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
         row[nd.off_b[d] + tid] += sb_;
       }
+      __syncthreads();                        // every wave is done reading TI (dW): it becomes the output tile
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
+      V4* const Bnxt = TI;
       const real* __restrict__ Wd = th + nd.off_w[d];
       for (int kt = wave; kt < NT; kt += 4) {
         V4 sk[4];                             // stash of layer d-1 for this lane's four features (point m)
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
           Bnxt[k * PD + m] = k < W ? preact_adjoint(sk[r], V4{a0[r], a1[r], a2[r], a3[r]}) : V4{0, 0, 0, 0};
         }
       }
-      __syncthreads();                        // every wave is done reading TI before it is refilled
+      __syncthreads();                        // every wave is done reading Bcur (adjoint GEMM): it is refilled
       if (d >= 2)                             // inputs of layer d-1 = output channels of layer d-2
         for (int j = tid >> 4; j < WP; j += 16) {
           V4 c{0, 0, 0, 0};
@@ -322,9 +328,9 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
             real d1, d2;
             c = channels_of(S[((size_t)(d - 2) * W + j) * s_pad + lp0 + pe], d1, d2);
           }
-          TI[j * PD + pe] = c;
+          Bcur[j * PD + pe] = c;
         }
-      V4* tmp = Bcur; Bcur = Bnxt; Bnxt = tmp;
+      V4* tmp = Bcur; Bcur = TI; TI = tmp;     // roles swap: the old TI holds z_bar, the old Bcur the inputs
     }
     __syncthreads();                          // z_bar of dense 0 published (also covers H == 1)
     if (tid < W) {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
