@@ -338,15 +338,16 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
 
 // shape-generic MFMA sweeps for one chunk (kernels_tile16.h)
 template <typename real, int NT, bool WLDS>
-static int t16_launch_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
+static int t16_launch_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int chunk, void* O, int base, int pts,
+                          real lbx, real lbt, real sx, real st) {
   static unsigned long long attr = 0;
   const size_t lds = t16_fwd_lds<NT>(sizeof(real), WLDS);
   if (first_call_on_device(attr))
     HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
   hipLaunchKernelGGL((k_t16_fwd<real, NT, WLDS>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd,
-                     (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, base, c->sd.n_pad, c->chunk,
-                     pts / 16, lbx, lbt, sx, st, (vec4<real>*)c->S, (vec4<real>*)c->O);
+                     (const real*)c->theta_r, (const real*)xs, (const real*)ts, base, n_pad, chunk,
+                     pts / 16, lbx, lbt, sx, st, (vec4<real>*)c->S, (vec4<real>*)O);
   return 0;
 }
 template <typename real, int NT, int PDE, bool WLDS>
@@ -363,11 +364,27 @@ static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, re
   return 0;
 }
 template <typename real>
-static int t16_fwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st) {
+static int t16_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int chunk, void* O, int base, int pts,
+                   real lbx, real lbt, real sx, real st) {
   // widths up to 64: four feature tiles; up to 128: eight (in float64 the weights then stay in L2: LDS is full)
-  if (c->nd.width > 64) return t16_launch_fwd<real, 8, sizeof(real) == 4>(c, base, pts, lbx, lbt, sx, st);
-  return t16_launch_fwd<real, 4, true>(c, base, pts, lbx, lbt, sx, st);
+  if (c->nd.width > 64)
+    return t16_launch_fwd<real, 8, sizeof(real) == 4>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
+  return t16_launch_fwd<real, 4, true>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
 }
+// plain forward sweep of one chunk for pinn_predict / pinn_residual: the MFMA sweep for nets wide enough to profit
+template <typename real>
+static int forward_chunk(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int chunk, void* O, int base, int pts) {
+  const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
+  const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
+  if (tile16_ok(c) && c->nd.width >= 24)
+    return t16_fwd<real>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
+  constexpr int JT = sizeof(real) == 4 ? 20 : 10;
+  hipLaunchKernelGGL((k_forward<real, JT>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const real*)c->theta_r,
+                     (const real*)xs, (const real*)ts, base, n_pad, chunk, lbx, lbt, sx, st, (vec4<real>*)c->S,
+                     (vec4<real>*)O);
+  return 0;
+}
+
 template <typename real, int PDE>
 static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
   if (c->nd.width > 64)
@@ -404,7 +421,7 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       const dim3 grid(pts / 64), block(64);
       bool fwd_done = false;
       if (t16_fwd_on(c)) {
-        if (int rc = t16_fwd<real>(c, base, pts, lbx, lbt, sx, st)) return rc;
+        if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts, lbx, lbt, sx, st)) return rc;
         fwd_done = true;
       }
       if constexpr (sizeof(real) == 4) {
@@ -1190,13 +1207,11 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
   std::vector<double> hx(n_pad, c->lb[0]), ht(n_pad, c->lb[1]);
   for (int64_t i = 0; i < n; ++i) { hx[i] = X[2 * i]; ht[i] = X[2 * i + 1]; }
   if (upload_real(c, c->xe, hx.data(), n_pad) || upload_real(c, c->te, ht.data(), n_pad)) return PINN_EHIP;
-  const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
   for (int base = 0; base < n_pad; base += chunk) {
     const int pts = (n_pad - base < chunk) ? n_pad - base : chunk;
-    if (c->dtype == PINN_F64)
-      hipLaunchKernelGGL((k_forward<double, 10>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const double*)c->theta_r, (const double*)c->xe, (const double*)c->te, base, n_pad, chunk, c->lb[0], c->lb[1], sx, st, (vec4<double>*)c->S, (vec4<double>*)c->Oe);
-    else
-      hipLaunchKernelGGL((k_forward<float, 20>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const float*)c->theta_r, (const float*)c->xe, (const float*)c->te, base, n_pad, chunk, (float)c->lb[0], (float)c->lb[1], (float)sx, (float)st, (vec4<float>*)c->S, (vec4<float>*)c->Oe);
+    const int rc = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts)
+                                        : forward_chunk<float>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts);
+    if (rc) return rc;
   }
   HIPCHK(hipGetLastError());
   std::vector<char> ho((size_t)NO * n_pad * 4 * rs);
@@ -1254,17 +1269,15 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
   if (cnt == 0) return 0;
   const int NO = c->nd.n_out;
   if ((size_t)cnt * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)cnt * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)cnt * NO; }
-  const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
   {  // the forward sweep below stashes one chunk of Taylor channels (the fused paths keep none)
     const size_t need_S = (size_t)c->nd.n_hidden * c->nd.width * (size_t)c->chunk * 4 * real_size(c);
     if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
   }
   for (int base = 0; base < sd.n_pad; base += c->chunk) {
     const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
-    if (c->dtype == PINN_F64)
-      hipLaunchKernelGGL((k_forward<double, 10>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, base, sd.n_pad, c->chunk, c->lb[0], c->lb[1], sx, st, (vec4<double>*)c->S, (vec4<double>*)c->O);
-    else
-      hipLaunchKernelGGL((k_forward<float, 20>), dim3(pts / 64), dim3(64), 0, c->stream, c->nd, (const float*)c->theta_r, (const float*)c->xs, (const float*)c->ts, base, sd.n_pad, c->chunk, (float)c->lb[0], (float)c->lb[1], (float)sx, (float)st, (vec4<float>*)c->S, (vec4<float>*)c->O);
+    const int rc2 = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts)
+                                         : forward_chunk<float>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts);
+    if (rc2) return rc2;
   }
   const dim3 grid((cnt + 255) / 256), block(256);
 #define RES(REAL, P) hipLaunchKernelGGL((k_residual<REAL, P>), grid, block, 0, c->stream, first, cnt, sd.n_pad, (const vec4<REAL>*)c->O, (const REAL*)c->theta_r, c->nd.n_net, (REAL)c->nu, c->f_out, NO)
