@@ -74,3 +74,71 @@ def test_shard_bounds_cover_and_balance():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- communicator set-up protocol (parallel.init_engine_comm) with a scripted engine, world_size 2 over gloo ----------
+class _ScriptedEngine(object):
+    """Stands in for pinn_native.Engine: records the calls, fails where the scenario says so."""
+
+    def __init__(self, rank, scenario):
+        self.rank, self.s, self.calls, self.mode = rank, scenario, [], "none"
+
+    def _fail(self, what):
+        import pinn_native
+        if self.s.get(what) == self.rank:
+            raise pinn_native.PinnNativeError("scripted failure of %s on rank %d" % (what, self.rank))
+
+    def comm_init(self, uid, world, rank):
+        self.calls.append("comm_init"); self.mode = "rccl"
+
+    def comm_xgmi_export(self, world, rank):
+        self.calls.append("export"); self._fail("export"); return b"h%d" % rank + bytes(62)
+
+    def comm_xgmi_attach(self, handles):
+        self.calls.append("attach"); self._fail("attach"); return self.s.get("unmapped") != self.rank
+
+    def comm_xgmi_selftest(self):
+        self.calls.append("selftest"); return self.s.get("bad_selftest") != self.rank
+
+    def comm_benchmark(self, mode, iters=200):
+        self.calls.append("bench_" + mode)
+        return {"rccl": 20.0, "mailbox": self.s.get("mailbox_us", 5.0)}[mode]
+
+    def comm_set_mode(self, mode):
+        self.calls.append("set_" + mode); self.mode = mode
+
+
+def _comm_worker(rank, world, port, out_dir, scenario):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("PINN_COMM", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pinn_native
+    from pinn_native import parallel
+    pinn_native.Engine.comm_unique_id = staticmethod(lambda: b"u" * 128)
+    eng = _ScriptedEngine(rank, scenario)
+    mode = parallel.init_engine_comm(eng, dist, world, rank)
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%s|%s|%s" % (mode, eng.mode, ",".join(eng.calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,expect", [
+    ({}, "mailbox"),                                   # everything works, mailboxes faster -> mailboxes everywhere
+    ({"mailbox_us": 50.0}, "rccl"),                    # ... but slower on this node -> RCCL everywhere
+    ({"export": 1}, "rccl"),                           # one rank cannot export -> nobody attaches
+    ({"unmapped": 0}, "rccl"),                         # one rank cannot map a peer -> nobody runs the self-test
+    ({"bad_selftest": 1}, "rccl"),                     # one rank's self-test fails -> RCCL everywhere
+])
+def test_comm_setup_is_unanimous(tmp_path, scenario, expect):
+    port = 29600 + (os.getpid() + len(str(scenario))) % 300
+    mp.spawn(_comm_worker, args=(2, port, str(tmp_path), scenario), nprocs=2, join=True)
+    outs = [open(tmp_path / ("rank%d.txt" % r)).read().split("|") for r in range(2)]
+    assert outs[0][0] == outs[1][0] == expect and outs[0][1] == outs[1][1] == expect, outs
+    if "unmapped" in scenario:
+        assert all("selftest" not in o[2] for o in outs)
+    if "export" in scenario:
+        assert all("attach" not in o[2] for o in outs)
