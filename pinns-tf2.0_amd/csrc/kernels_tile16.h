@@ -70,16 +70,32 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
 
   real pre[GEO::NPRE];                        // (dead when !WLDS)
   if constexpr (WLDS) { if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[1], W, W, W, tid); }
+  // parameters that every group reuses: dense 0 of this thread's features, the output layer's k-slice
+  real p0x[NT], p0t[NT], p0b[NT], pout[2 * NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int j = (tid >> 4) + 16 * i;
+    p0x[i] = j < W ? th[nd.off_w[0] + j] : real(0);
+    p0t[i] = j < W ? th[nd.off_w[0] + W + j] : real(0);
+    p0b[i] = j < W ? th[nd.off_b[0] + j] : real(0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * NT; ++i) {
+    const int k = (tid >> 5) + 8 * i, o = (tid >> 4) & 1;
+    pout[i] = (k < W && o < NO) ? th[nd.off_w[H] + k * NO + o] : real(0);
+  }
 
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int lp0 = grp * 16;
     {  // dense 0: items (feature j, point pe), point fastest
       const real x = xs[base + lp0 + pe], t = ts[base + lp0 + pe];
       const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
-      for (int j = tid >> 4; j < WP; j += 16) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int j = (tid >> 4) + 16 * i;
         V4 s{0, 0, 0, 0}, c{0, 0, 0, 0};
         if (j < W) {
-          const real w0 = th[nd.off_w[0] + j], w1 = th[nd.off_w[0] + W + j], b0 = th[nd.off_b[0] + j];
+          const real w0 = p0x[i], w1 = p0t[i], b0 = p0b[i];
           s = V4{tanh_r(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
           S[(size_t)j * s_pad + lp0 + pe] = s;
           real d1, d2;
@@ -138,12 +154,13 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
     {  // linear output layer: thread = (k-slice ks8, output o, point pe); 8 slices summed through LDS
       const int o = (tid >> 4) & 1, ks8 = tid >> 5;
       V4 acc{0, 0, 0, 0};
-      if (o < NO)
-        for (int k = ks8; k < W; k += 8) {
-          const real w = th[nd.off_w[H] + k * NO + o];
-          const V4 b = Tin[k * PD + pe];
-          acc.x += b.x * w; acc.y += b.y * w; acc.z += b.z * w; acc.w += b.w * w;
-        }
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) {
+        const int k = ks8 + 8 * i;                // pout is zero beyond the width / the outputs
+        const V4 b = Tin[k * PD + pe];
+        const real w = pout[i];
+        acc.x += b.x * w; acc.y += b.y * w; acc.z += b.z * w; acc.w += b.w * w;
+      }
       reinterpret_cast<V4*>(red)[(ks8 * 2 + o) * 16 + pe] = acc;
       __syncthreads();
       if (ks8 == 0 && o < NO) {
