@@ -24,3 +24,19 @@ for layers in ([2] + [20] * 8 + [1], [2] + [20] * 4 + [1], [2] + [20] * 10 + [1]
         print("%-28s %s path=%d: %8.1f us/step  %.3g pts/s  %.2f TFLOP/s" % (
             "x".join(map(str, layers)), dt, eng.kernel_path(), s * 1e6, 10000 / s, 24.0 * mw * 10000 / s / 1e12))
         eng.close()
+
+# steady state (many 16-point groups per workgroup): the shape-generic MFMA path at N_f = 200000
+np.random.seed(1234)
+r = burgersutil.prep_data(os.path.join(bench.PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, 200000, noise=0.0)
+X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+for layers, dt in (([2] + [50] * 4 + [1], "f32"), ([2] + [64] * 6 + [1], "f32"), ([2] + [128] * 3 + [1], "f32"),
+                   ([2] + [64] * 6 + [1], "f64"), ([2] + [100] * 4 + [1], "f64")):
+    eng = pinn_native.Engine(layers, lb, ub, pde="burgers", dtype=dt)
+    eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(bench.NU); eng.set_weights(init.glorot_flat(layers))
+    eng.adam_init(1e-3, 0.9, 0.999, 1e-7); eng.adam_run(3, want_losses=False); eng.sync()
+    t0 = time.perf_counter(); eng.adam_run(5, want_losses=False); eng.sync()
+    s = (time.perf_counter() - t0) / 5
+    mw = sum(a * b for a, b in zip(layers[:-1], layers[1:]))
+    print("N_f=200000 %-24s %s path=%d: %8.1f us/step  %.3g pts/s  %.2f TFLOP/s" % (
+        "x".join(map(str, layers)), dt, eng.kernel_path(), s * 1e6, 200000 / s, 24.0 * mw * 200000 / s / 1e12))
+    eng.close()
