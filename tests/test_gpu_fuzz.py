@@ -75,3 +75,27 @@ def test_random_shapes_against_oracle(pde_kind, W, H, n_f, n_u, seed, dtype):
         assert rel(grad, ref[1]) <= tg, (path, rel(grad, ref[1]))
     assert tried >= 1
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_shape_generic_path_over_several_chunks(dtype):
+    """more points than one forward/reverse launch pair covers (32768): the partial rows are accumulated across chunks"""
+    import pinn_native
+    from oracle import pde
+    rs = np.random.RandomState(99)
+    layers = [2, 24, 24, 24, 1]
+    w = 0.4 * rs.standard_normal(sum(a * b + b for a, b in zip(layers[:-1], layers[1:])))
+    pts = lambda n: np.column_stack([rs.uniform(LB[0], UB[0], n), rs.uniform(LB[1], UB[1], n)])
+    X_f, X_u = pts(70001), pts(77)
+    u = rs.standard_normal((77, 1))
+    eng = pinn_native.Engine(layers, LB, UB, pde="burgers", dtype=dtype)
+    assert eng.kernel_path() == 4
+    eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(NU); eng.set_weights(w)
+    loss, grad, _ = eng.loss_grad()
+    lo, go, ex = pde.burgers_loss_grad(w, layers, LB, UB, X_f, X_u, u, NU)
+    tl, tg = (1e-11, 1e-10) if dtype == "f64" else (2e-5, 5e-5)
+    assert abs(loss - lo) <= tl * abs(lo) and rel(grad, go) <= tg
+    loss2, grad2, _ = eng.loss_grad()
+    assert loss2 == loss and np.array_equal(grad, grad2)            # bit-reproducible
+    assert rel(eng.residual(), ex["f"]) <= tg * 10                   # MFMA forward in pinn_residual
+    eng.close()
