@@ -185,7 +185,22 @@ static bool wide_ok(const pinn_ctx* c) {
 static bool tile16_ok(const pinn_ctx* c) { return !is_disc(c) && c->nd.width <= 128 && c->nd.n_out <= 2; }
 static bool t16_fwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 5; }
 static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6; }
-static int t16_wgs(const pinn_ctx* c, int pts) { const int g = pts / 16, cap = 2 * c->n_cu; return g < cap ? g : cap; }
+// Launch plan of the shape-generic sweeps for a chunk of `pts` points (measured, profiles/r01_t16_plan.txt):
+//   widths <= 64, float32: few groups (<= 3 per CU: every group resident at once) -> weights straight from L2, three
+//     workgroups per CU; many groups -> weights staged in LDS, two workgroups per CU;
+//   widths <= 64, float64: weights from L2 (the LDS copy would leave room for one workgroup per CU only), two per CU;
+//   widths > 64: two per CU (float32: weights in LDS; float64: from L2, LDS is full).
+static bool t16_lds_weights(const pinn_ctx* c, int pts) {
+  if (c->nd.width > 64) return c->dtype != PINN_F64;
+  if (c->dtype == PINN_F64) return false;
+  return pts / 16 > 3 * c->n_cu;
+}
+static int t16_wgs(const pinn_ctx* c, int pts) {
+  const int g = pts / 16;
+  const int per_cu = (c->nd.width <= 64 && c->dtype != PINN_F64 && g <= 3 * c->n_cu) ? 3 : 2;
+  const int cap = per_cu * c->n_cu;
+  return g < cap ? g : cap;
+}
 
 template <typename T>
 static int dev_alloc(T** p, size_t bytes) {
@@ -369,6 +384,8 @@ static int t16_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int c
   // widths up to 64: four feature tiles; up to 128: eight (in float64 the weights then stay in L2: LDS is full)
   if (c->nd.width > 64)
     return t16_launch_fwd<real, 8, sizeof(real) == 4>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
+  if (!t16_lds_weights(c, pts))
+    return t16_launch_fwd<real, 4, false>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
   return t16_launch_fwd<real, 4, true>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
 }
 // plain forward sweep of one chunk for pinn_predict / pinn_residual: the MFMA sweep for nets wide enough to profit
@@ -389,6 +406,8 @@ template <typename real, int PDE>
 static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
   if (c->nd.width > 64)
     return t16_launch_bwd<real, 8, PDE, sizeof(real) == 4>(c, base, pts, lbx, lbt, sx, st, accumulate);
+  if (!t16_lds_weights(c, pts))
+    return t16_launch_bwd<real, 4, PDE, false>(c, base, pts, lbx, lbt, sx, st, accumulate);
   return t16_launch_bwd<real, 4, PDE, true>(c, base, pts, lbx, lbt, sx, st, accumulate);
 }
 
