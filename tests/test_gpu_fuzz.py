@@ -99,3 +99,30 @@ def test_shape_generic_path_over_several_chunks(dtype):
     assert loss2 == loss and np.array_equal(grad, grad2)            # bit-reproducible
     assert rel(eng.residual(), ex["f"]) <= tg * 10                   # MFMA forward in pinn_residual
     eng.close()
+
+
+def test_shape_generic_path_trains_like_the_reference_implementation():
+    """float64, 2x50^3x1: 60 Adam + 40 L-BFGS iterations on the shape-generic MFMA sweeps and on the one-lane-per-point
+    kernels from the same start -- the same trajectory (different summation orders: 1e-9 on the losses)"""
+    import pinn_native
+    from oracle import init
+    rs = np.random.RandomState(5)
+    layers = [2, 50, 50, 50, 1]
+    pts = lambda n: np.column_stack([rs.uniform(LB[0], UB[0], n), rs.uniform(LB[1], UB[1], n)])
+    X_f, X_u = pts(3000), pts(100)
+    u = -np.sin(np.pi * X_u[:, 0:1])
+    out = {}
+    for path in (0, 4):
+        eng = pinn_native.Engine(layers, LB, UB, pde="burgers", dtype="f64")
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(NU); eng.set_weights(init.glorot_flat(layers))
+        eng.set_kernel_path(path)
+        eng.adam_init(0.005, 0.9, 0.999, 1e-7)
+        la = eng.adam_run(60)
+        eng.lbfgs_begin(40, 0.8, 50, float(np.finfo(float).eps))
+        _, ll, done = eng.lbfgs_run(40)
+        out[path] = (la, ll, done, eng.get_weights())
+        eng.close()
+    assert out[0][2] == out[4][2]
+    assert np.max(np.abs(out[0][0] - out[4][0]) / out[0][0]) < 1e-9
+    assert len(out[0][1]) == len(out[4][1]) and np.max(np.abs(out[0][1] - out[4][1]) / out[0][1]) < 1e-7
+    assert out[4][0][-1] < out[4][0][0]
