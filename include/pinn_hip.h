@@ -108,6 +108,9 @@ int pinn_loss_grad(pinn_ctx* c, double* loss, double* grad, double* terms);
  * returns without synchronising the stream. */
 int pinn_adam_init(pinn_ctx* c, double lr, double beta1, double beta2, double eps);
 int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses);
+/* the same, returning the three loss parts of every step, terms3[i] = (residual, data, boundary) before update i:
+ * what the reference's Schrodinger loss prints on every evaluation (inf_cont_schrodinger.py:128) */
+int pinn_adam_run_terms(pinn_ctx* c, int n_steps, double* terms3);
 
 /* custom_lbfgs.lbfgs (utils/custom_lbfgs.py:39-236) as driven by nt_optimization_steps
  * (utils/neuralnetwork.py:131-136), device-resident.  pinn_lbfgs_begin does the initial

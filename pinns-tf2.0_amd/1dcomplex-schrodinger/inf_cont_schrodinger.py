@@ -39,6 +39,7 @@ class SchrodingerInformedNN(NeuralNetwork):
 
     def __init__(self, hp, logger, X_f, tb, ub, lb):
         super().__init__(hp, logger, ub, lb)
+        self._quiet_parts = bool(hp.get("quiet_loss_parts", False))   # hp switch: drop the per-epoch mse lines
         tb = np.asarray(tb, dtype=np.float64)
         X_lb = np.concatenate((0 * tb + lb[0], tb), 1)     # (lb_x, tb)
         X_ub = np.concatenate((0 * tb + ub[0], tb), 1)     # (ub_x, tb)
@@ -61,6 +62,15 @@ class SchrodingerInformedNN(NeuralNetwork):
         total, _, terms = self._engine.loss_grad(want_grad=False)
         print(f"mse_0 {terms[1]}    mse_b {terms[2]}    mse_f    {terms[0]}")
         return total
+
+    def _adam_chunk(self, n):
+        """The reference prints the three parts inside loss(), i.e. once per epoch (:128): same lines, same order
+        relative to the progress lines, emitted when the chunk's losses come back from the device."""
+        terms = self._engine.adam_run_terms(n)
+        if not self._quiet_parts:
+            for res, data, bnd in terms:
+                print(f"mse_0 {data}    mse_b {bnd}    mse_f    {res}")
+        return terms.sum(axis=1)
 
     def predict(self, X_star):
         h_pred = self.model(X_star)

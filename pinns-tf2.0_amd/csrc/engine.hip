@@ -102,7 +102,7 @@ struct pinn_ctx {
   // Adam
   double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-7;
   int64_t adam_t = 0;
-  bool adam_ready = false;
+  bool adam_ready = false, adam_want_terms = false;
   double* loss_hist = nullptr;
   size_t cap_loss_hist = 0;
 
@@ -1056,9 +1056,18 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
     std::vector<double> h3((size_t)3 * n_steps);
     HIPCHK(hipMemcpyAsync(h3.data(), c->loss_hist, h3.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (int s = 0; s < n_steps; ++s) losses[s] = h3[3 * s] + h3[3 * s + 1] + h3[3 * s + 2];
+    if (c->adam_want_terms) memcpy(losses, h3.data(), h3.size() * 8);
+    else for (int s = 0; s < n_steps; ++s) losses[s] = h3[3 * s] + h3[3 * s + 1] + h3[3 * s + 2];
   }
   return 0;
+}
+
+int pinn_adam_run_terms(pinn_ctx* c, int n_steps, double* terms3) {
+  REQUIRE(c && terms3, "null");
+  c->adam_want_terms = true;
+  const int rc = pinn_adam_run(c, n_steps, terms3);
+  c->adam_want_terms = false;
+  return rc;
 }
 
 int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double tol_fun,

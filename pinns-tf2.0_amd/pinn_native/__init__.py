@@ -87,6 +87,7 @@ _SIGNATURES = {
     "pinn_loss_grad": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, _c_double_p]),
     "pinn_adam_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double,
                                       ctypes.c_double, ctypes.c_double]),
+    "pinn_adam_run_terms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p]),
     "pinn_adam_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p]),
     "pinn_lbfgs_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_int, ctypes.c_double, ctypes.c_double,
@@ -313,6 +314,12 @@ class Engine(object):
     # ---- optimisers ------------------------------------------------------------------------
     def adam_init(self, lr, beta1=0.9, beta2=0.999, eps=1e-7):
         self._check(self._lib.pinn_adam_init(self._h, lr, beta1, beta2, eps))
+
+    def adam_run_terms(self, n_steps):
+        """[n_steps, 3] = (residual, data, boundary) loss parts before each update."""
+        terms = np.empty((max(int(n_steps), 1), 3), dtype=np.float64)
+        self._check(self._lib.pinn_adam_run_terms(self._h, int(n_steps), _dp(terms)))
+        return terms[:n_steps]
 
     def adam_run(self, n_steps, want_losses=True):
         if not want_losses:

@@ -247,11 +247,16 @@ class NeuralNetwork(object):
             stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
             if every:
                 stop = min(stop, (epoch // every + 1) * every)
-            losses = self._engine.adam_run(stop - epoch)
+            losses = self._adam_chunk(stop - epoch)
             for k, loss_value in enumerate(losses):
                 last = epoch + k == stop - 1     # the weights on the device are those after this epoch
                 self.logger.log_train_epoch(epoch + k, loss_value, self._log_custom() if last else "")
             epoch = stop
+
+    def _adam_chunk(self, n):
+        """n device-resident Adam steps; the loss before each update.  Subclasses that print per-evaluation
+        diagnostics (the Schrodinger loss parts) override this."""
+        return self._engine.adam_run(n)
 
     def tf_optimization_step(self, X_u, u):
         self._bind(X_u, u)
