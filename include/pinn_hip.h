@@ -46,7 +46,7 @@ enum {
 
 /* diagnostics */
 const char* pinn_last_error(void);
-int pinn_abi_version(void);
+int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6 */
 int pinn_device_count(int* n);
 /* name[0..cap) <- hipDeviceProp_t.gcnArchName etc. for Logger's banner (utils/logger.py:13-15) */
 int pinn_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);

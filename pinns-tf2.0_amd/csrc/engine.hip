@@ -782,7 +782,7 @@ static int cast_weights(pinn_ctx* c) {
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err.c_str(); }
-int pinn_abi_version(void) { return 1; }
+int pinn_abi_version(void) { return 2; }
 
 int pinn_device_count(int* n) {
   REQUIRE(n, "null");
