@@ -291,7 +291,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X_f[:args.nf_per_gpu], X_u, u, lb, ub, w0)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        # RCCL writes its version banner through C stdio: flush that first, so the JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     eng.close()
     if dist is not None:
         dist.barrier()
