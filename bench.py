@@ -248,6 +248,15 @@ def main():
                    "ms_per_step": 1e3 * el64 / args.steps, "dtype": "f64", "kernel_path": e64.kernel_path()}
         e64.close()
 
+    # every rank empties its C stdio buffer (RCCL's banner) before rank 0 prints: the JSON line stays the last line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
     if rank == 0:
         n_f_local = shard(n_f_total, world, 0)[1]
         n_u_local = shard(100, world, 0)[1]
