@@ -159,10 +159,9 @@ def main():
     if args.warmup > 0:
         # a fresh box idles at 570 MHz: keep the GPU busy for ~0.3 s first so that the W warm-up steps and the timed
         # region run at the sustained clock (extra untimed work only; the timed region is still exactly K steps)
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 0.3:
-            eng.adam_run(200, want_losses=False)
-            eng.sync()
+        # (a fixed number of steps, not a time limit: with a communicator every rank must run the same evaluations)
+        eng.adam_run(6000, want_losses=False)
+        eng.sync()
         eng.set_weights(w0)
         eng.adam_init(0.03, 0.9, 0.999, 1e-7)
         w_adam = max(args.warmup // 3, 1)
