@@ -72,6 +72,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
   }
   double tot = 0;
   const long long t0 = wall_clock64();
+  // once a peer has been declared lost nobody waits again: one bounded stall, then the host sees the error code
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timeout_ticks = 0;
   for (int r = 0; r < nr; ++r) {
     if (r == me) { tot += g; continue; }
     const xg_line_t* src = px.box[me] + (size_t)(par * nr + r) * px.Rp + c;
