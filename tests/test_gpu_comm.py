@@ -103,3 +103,17 @@ def test_auto_policy_probes_both_implementations(burgers_sets, monkeypatch):
     got = eng.loss_grad()
     assert got[0] == ref[0] and np.array_equal(got[1], ref[1])
     eng.close()
+
+
+def test_mailbox_lost_peer_is_an_error_not_a_hang():
+    """a rank that stops taking part costs its peers one bounded wait, then a negative verdict / error code"""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29900 + os.getpid() % 90
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(here, "helpers", "mailbox_lost_peer.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and "LOST_PEER_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
