@@ -289,6 +289,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": (achieved / peak) if achieved else None, "traffic": pmc_traffic(args, world),
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "hbm_gbps": (pmc_traffic(args, world) / sweeps_s / 1e9) if (pmc_traffic(args, world) and sweeps_s > 0) else None,
+                         "hbm_peak_gbps": 8000.0,
                          "kernel": {2: "pinn::k_fused20m", 1: "pinn::k_fused20", 0: "pinn::k_forward+k_backward"}[eng.kernel_path()],
                          "avg_launch_ms": kernel_ms, "avg_launch_method": "hipExtLaunchKernelGGL start/stop events" if tim["kernel_exact"] else "event bracket minus empty bracket", "event_bracket_ms": tim["sweeps_ms"],
                          "empty_event_bracket_ms": tim["empty_bracket_ms"], "evals_timed": tim["n"],
