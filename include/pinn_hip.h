@@ -46,7 +46,7 @@ enum {
 
 /* diagnostics */
 const char* pinn_last_error(void);
-int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6 */
+int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6; 3: + pinn_residual_at */
 int pinn_device_count(int* n);
 /* name[0..cap) <- hipDeviceProp_t.gcnArchName etc. for Logger's banner (utils/logger.py:13-15) */
 int pinn_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
@@ -134,6 +134,9 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out);
 /* f_model() at the stored collocation points (inf_cont_burgers.py:65-90): f[n_f, n_out]
  * (IDE: at the data points) */
 int pinn_residual(pinn_ctx* c, double* f, int64_t n);
+/* f_model(X) at n caller-supplied points X [n][2] -> f [n][n_out]: what the identification script's predict
+ * evaluates on X_star (1d-burgers/ide_cont_burgers.py:169-172) */
+int pinn_residual_at(pinn_ctx* c, const double* X, int64_t n, double* f);
 
 /* Data-parallel: one process per GPU, RCCL all-reduce(SUM) of [grad | loss terms].
  * Rank 0 calls pinn_comm_unique_id and ships the 128 bytes to the other ranks by any
@@ -166,7 +169,7 @@ int pinn_comm_get_mode(pinn_ctx* c, int* mode);
  * [2] whole evaluation, [3] what an EMPTY event bracket reads on this stream (calibrated at
  * enable time; subtract it from [1..2] to compare with rocprofv3 kernel durations),
  * [4] = 1 when [0] is the exact begin-to-end duration of the single loss+grad kernel (the events
- * were attached to the launch itself, hipExtLaunchKernelGGL: kernel path 2) and needs no correction;
+ * were attached to the launch itself, hipExtLaunchKernelGGL: kernel paths 1 and 2) and needs no correction;
  * n = evaluations sampled. */
 int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);

@@ -106,12 +106,13 @@ def _field_figure(X_star, u_pred, X, T, x, t, X_u_train, title):
 
 
 def plot_inf_cont_results(X_star, u_pred, X_u_train, u_train, Exact_u, X, T, x, t,
-                          save_path=None, save_hp=None):
+                          save_path=None, save_hp=None, weights=None):
     """Headless (no-LaTeX) counterpart of burgersutil.py:133-206: u(t,x) heat-map with the
-    training points; persisted through saveResultDir like the reference."""
+    training points; persisted through saveResultDir like the reference.  `weights` (optional, not in the
+    reference): the trained flat vector, written next to the figure as weights.npy."""
     _field_figure(X_star, u_pred, X, T, x, t, X_u_train, "u(t,x)")
     if save_path is not None and save_hp is not None:
-        saveResultDir(save_path, save_hp)
+        saveResultDir(save_path, save_hp, weights=weights)
 
 
 def plot_ide_cont_results(X_star, u_pred, X_u_train, u_train, Exact_u, X, T, x, t,

@@ -1,6 +1,7 @@
 """Burgers continuous-time identification on the MI355X engine -- counterpart of the
 reference's 1d-burgers/ide_cont_burgers.py (whose source has inconsistent indentation and
-does not parse; the intent is unambiguous): learn lambda_1 and lambda_2 with
+does not parse as shipped; a whitespace-only repair, tests/golden/repair_ide_cont.py, runs and is
+what the fixtures of this model come from): learn lambda_1 and lambda_2 with
 f = u_t + lambda_1 u u_x - exp(lambda_2) u_xx evaluated at the data points (:56-91), the two
 scalars appended to the flat weight vector (:93-107), error = mean relative lambda error
 (:187-192), then a second run on a fresh sample (the reference's "noise" run, :200-205).
@@ -54,8 +55,11 @@ class BurgersInformedNN(NeuralNetwork):
         return self._engine.get_weights()[-1:]
 
     def f_model(self, X_u=None):
-        """Residual at the bound data points, [N_u, 1]."""
-        return self._engine.residual()
+        """Residual f = u_t + l1 u u_x - exp(l2) u_xx at the points X_u [N, 2] (:56-85); without an argument, at
+        the bound data points.  [N, 1]."""
+        if X_u is None:
+            return self._engine.residual()
+        return self._engine.residual_at(np.asarray(X_u, dtype=np.float64))
 
     def loss(self, u, u_pred):
         f_pred = self.f_model()
@@ -72,9 +76,8 @@ class BurgersInformedNN(NeuralNetwork):
         super().fit(X_u, u)
 
     def predict(self, X_star):
-        """(u at X_star, f at the training points).  The reference re-evaluates f at X_star
-        (:169-172); here f is reported on the bound set, u on X_star."""
-        return self.model(X_star), self.f_model()
+        """(u, f) at X_star, as the reference (:169-172)."""
+        return self.model(X_star), self.f_model(X_star)
 
 
 if __name__ == "__main__":

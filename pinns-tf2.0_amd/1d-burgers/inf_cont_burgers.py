@@ -85,7 +85,7 @@ def run(hp):
     u_pred = pinn.predict(X_star)[0]
     if not os.environ.get("PINN_NO_PLOT"):
         plot_inf_cont_results(X_star, u_pred.flatten(), X_u_train, u_train, Exact_u, X, T, x, t,
-                              save_path=os.path.join(_root, eqnPath), save_hp=hp)
+                              save_path=os.path.join(_root, eqnPath), save_hp=hp, weights=pinn.get_weights())
     return pinn
 
 

@@ -372,7 +372,11 @@ static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, re
   if (first_call_on_device(attr))
     HIPCHK(hipFuncSetAttribute((const void*)k_t16_bwd<real, NT, PDE, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  hipLaunchKernelGGL((k_t16_bwd<real, NT, PDE, WLDS>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd, c->sd,
+  // one partial row per workgroup: never launch more workgroups than the rows sized for a full chunk (t16_wgs is
+  // not monotone in pts: a short last chunk may prefer three workgroups per CU where the full chunk took two)
+  const int rows_cap = t16_wgs(c, c->chunk);
+  const int wgs = t16_wgs(c, pts) < rows_cap ? t16_wgs(c, pts) : rows_cap;
+  hipLaunchKernelGGL((k_t16_bwd<real, NT, PDE, WLDS>), dim3(wgs), dim3(256), lds, c->stream, c->nd, c->sd,
                      (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, (const real*)c->tgt, base,
                      c->sd.n_pad, c->chunk, pts / 16, lbx, lbt, sx, st, (real)c->nu, (const vec4<real>*)c->S,
                      (const vec4<real>*)c->O, (real*)c->part, c->R, accumulate);
@@ -418,7 +422,7 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const SetDesc sd = c->sd;
   const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
   const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
-  if (ev4 && c->path != 2) HIPCHK(hipEventRecord(ev4[0], c->stream));
+  if (ev4 && c->path != 2 && c->path != 1) HIPCHK(hipEventRecord(ev4[0], c->stream));
   if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2)
@@ -431,9 +435,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
                                              (const real*)c->ts, (const real*)c->tgt, lbx, lbt, sx,
                                              st, (real)c->nu, (vec4<real>*)c->S, (real*)c->part, c->R,
-                                             c->stream, c->stamps);
+                                             c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
     if (rc) return fail(PINN_EHIP, "fused20 launch failed: %s", hipGetErrorString((hipError_t)rc));
-    if (ev4) HIPCHK(hipEventRecord(ev4[1], c->stream));
   } else {
     for (int base = 0, ci = 0; base < sd.n_pad; base += c->chunk, ++ci) {
       const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
@@ -776,13 +779,41 @@ static int cast_weights(pinn_ctx* c) {
   return 0;
 }
 
+// Taylor-channel forward sweep over n caller-supplied points -> c->Oe ([n_out][n_pad] vec4 (u, u_x, u_t, u_xx))
+static int forward_eval(pinn_ctx* c, const double* X, int64_t n, int* n_pad_out) {
+  const size_t rs = real_size(c);
+  const int NO = c->nd.n_out;
+  const size_t W = c->nd.width, H = c->nd.n_hidden;
+  const int n_pad = (int)((n + 63) / 64 * 64);
+  const int chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
+  if ((size_t)n_pad > c->cap_eval) {
+    if (dev_alloc(&c->xe, n_pad * rs) || dev_alloc(&c->te, n_pad * rs) ||
+        dev_alloc(&c->Oe, (size_t)NO * n_pad * 4 * rs)) return PINN_EHIP;
+    c->cap_eval = n_pad;
+  }
+  const size_t need_S = H * W * (size_t)chunk * 4 * rs;
+  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
+  std::vector<double> hx(n_pad, c->lb[0]), ht(n_pad, c->lb[1]);
+  for (int64_t i = 0; i < n; ++i) { hx[i] = X[2 * i]; ht[i] = X[2 * i + 1]; }
+  if (upload_real(c, c->xe, hx.data(), n_pad) || upload_real(c, c->te, ht.data(), n_pad)) return PINN_EHIP;
+  for (int base = 0; base < n_pad; base += chunk) {
+    const int pts = (n_pad - base < chunk) ? n_pad - base : chunk;
+    const int rc = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts)
+                                        : forward_chunk<float>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts);
+    if (rc) return rc;
+  }
+  HIPCHK(hipGetLastError());
+  *n_pad_out = n_pad;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err.c_str(); }
-int pinn_abi_version(void) { return 2; }
+int pinn_abi_version(void) { return 3; }
 
 int pinn_device_count(int* n) {
   REQUIRE(n, "null");
@@ -1056,6 +1087,7 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
     std::vector<double> h3((size_t)3 * n_steps);
     HIPCHK(hipMemcpyAsync(h3.data(), c->loss_hist, h3.size() * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (int rc = xg_check(c)) return rc;        // a lost mailbox peer: the steps after it were not applied
     if (c->adam_want_terms) memcpy(losses, h3.data(), h3.size() * 8);
     else for (int s = 0; s < n_steps; ++s) losses[s] = h3[3 * s] + h3[3 * s + 1] + h3[3 * s + 2];
   }
@@ -1132,6 +1164,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
                      c->lb_log_iter, c->lb_log_loss, 1);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc2 = xg_check(c)) return rc2;
   c->lb_ready = true;
   return 0;
 }
@@ -1189,6 +1222,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
   LbfgsState hs;
   HIPCHK(hipMemcpyAsync(&hs, c->lb_state + c->lb_flip, sizeof hs, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  if (int rc2 = xg_check(c)) return rc2;
   const int fresh = hs.n_logged - c->lb_logged_read;
   if (fresh > 0 && iters && losses) {
     HIPCHK(hipMemcpy(iters, c->lb_log_iter + c->lb_logged_read, (size_t)fresh * 4, hipMemcpyDeviceToHost));
@@ -1222,26 +1256,8 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
     return disc_predict_any(c, 0, 0, X, n, out);
   const size_t rs = real_size(c);
   const int NO = c->nd.n_out;
-  const size_t W = c->nd.width, H = c->nd.n_hidden;
-  const int n_pad = (int)((n + 63) / 64 * 64);
-  const int chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
-  if ((size_t)n_pad > c->cap_eval) {
-    if (dev_alloc(&c->xe, n_pad * rs) || dev_alloc(&c->te, n_pad * rs) ||
-        dev_alloc(&c->Oe, (size_t)NO * n_pad * 4 * rs)) return PINN_EHIP;
-    c->cap_eval = n_pad;
-  }
-  const size_t need_S = H * W * (size_t)chunk * 4 * rs;
-  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
-  std::vector<double> hx(n_pad, c->lb[0]), ht(n_pad, c->lb[1]);
-  for (int64_t i = 0; i < n; ++i) { hx[i] = X[2 * i]; ht[i] = X[2 * i + 1]; }
-  if (upload_real(c, c->xe, hx.data(), n_pad) || upload_real(c, c->te, ht.data(), n_pad)) return PINN_EHIP;
-  for (int base = 0; base < n_pad; base += chunk) {
-    const int pts = (n_pad - base < chunk) ? n_pad - base : chunk;
-    const int rc = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts)
-                                        : forward_chunk<float>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts);
-    if (rc) return rc;
-  }
-  HIPCHK(hipGetLastError());
+  int n_pad = 0;
+  if (int rc = forward_eval(c, X, n, &n_pad)) return rc;
   std::vector<char> ho((size_t)NO * n_pad * 4 * rs);
   HIPCHK(hipMemcpyAsync(ho.data(), c->Oe, ho.size(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1314,6 +1330,26 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
 #undef RES
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(f, c->f_out, (size_t)cnt * NO * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int pinn_residual_at(pinn_ctx* c, const double* X, int64_t n, double* f) {
+  if (c && is_disc(c)) return fail(PINN_EUNSUPPORTED, "pinn_residual_at: not defined for discrete-time models");
+  REQUIRE(c && X && f && n >= 0, "bad arguments");
+  HIPCHK(hipSetDevice(c->device));
+  if (n == 0) return 0;
+  const int NO = c->nd.n_out;
+  int n_pad = 0;
+  if (int rc = forward_eval(c, X, n, &n_pad)) return rc;
+  if ((size_t)n * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)n * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)n * NO; }
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define RES(REAL, P) hipLaunchKernelGGL((k_residual<REAL, P>), grid, block, 0, c->stream, 0, (int)n, n_pad, (const vec4<REAL>*)c->Oe, (const REAL*)c->theta_r, c->nd.n_net, (REAL)c->nu, c->f_out, NO)
+  if (c->dtype == PINN_F64) { if (c->pde == 0) RES(double, 0); else if (c->pde == 1) RES(double, 1); else RES(double, 2); }
+  else { if (c->pde == 0) RES(float, 0); else if (c->pde == 1) RES(float, 1); else RES(float, 2); }
+#undef RES
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(f, c->f_out, (size_t)n * NO * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1436,7 +1472,7 @@ int pinn_comm_benchmark(pinn_ctx* c, int mode, int iters, double* us_per_iter) {
 int pinn_comm_set_mode(pinn_ctx* c, int mode) {
   REQUIRE(c && (mode == 1 || mode == 2), "mode must be 1 (RCCL) or 2 (mailboxes)");
   if (mode == 2) REQUIRE(c->xg.attached, "mailboxes are not attached (pinn_comm_xgmi_attach)");
-  if (mode == 1) REQUIRE(c->comm || c->xg.attached, "no communicator");
+  if (mode == 1) REQUIRE(c->comm, "mode 1 needs an RCCL communicator (pinn_comm_init)");
   c->xg.on = mode == 2;
   return 0;
 }
@@ -1488,7 +1524,7 @@ int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n) {
   *n = c->ev_used;
   const double k = c->ev_used ? 1.0 / c->ev_used : 0.0;
   avg_ms[0] = a * k; avg_ms[1] = b * k; avg_ms[2] = t * k; avg_ms[3] = c->ev_overhead_ms;
-  avg_ms[4] = c->path == 2 ? 1.0 : 0.0;
+  avg_ms[4] = (c->path == 2 || c->path == 1) ? 1.0 : 0.0;
   c->ev_used = 0;
   return 0;
 }

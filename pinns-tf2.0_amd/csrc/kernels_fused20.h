@@ -27,6 +27,7 @@
 // Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of inf_cont_burgers.py:65-90 under
 // the outer tape of utils/neuralnetwork.py:55-59.
 #pragma once
+#include <hip/hip_ext.h>
 #include "kernels_generic.h"
 
 namespace pinn {
@@ -383,7 +384,7 @@ template <typename real, int PDE>
 inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, const real* xs,
                           const real* ts, const real* tgt, real lbx, real lbt, real sx, real st,
                           real nu, vec4<real>* S, real* part, int R, hipStream_t stream,
-                          long long* stamps = nullptr) {
+                          long long* stamps = nullptr, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
   const size_t lds = fused20_lds_bytes<real>(nd.n_hidden);
   static size_t attr_set[64] = {};                 // per device: the attribute belongs to the device's code object
   int dev = 0;
@@ -394,8 +395,12 @@ inline int fused20_launch(const NetDesc& nd, const SetDesc& sd, const real* th, 
     if (e != hipSuccess) return (int)e;
     attr_set[dev & 63] = lds;
   }
-  hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
-                     xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R, stamps);
+  if (ev_start && ev_stop)      // the events take the kernel's own begin / end timestamps (what a profiler reports)
+    hipExtLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, ev_start, ev_stop, 0,
+                          nd, sd, th, xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R, stamps);
+  else
+    hipLaunchKernelGGL((k_fused20<real, PDE>), dim3(sd.n_pad / 64), dim3(256), lds, stream, nd, sd, th,
+                       xs, ts, tgt, lbx, lbt, sx, st, nu, S, part, R, stamps);
   return (int)hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
     }
   }
   double tot = 0;
+  bool lost = false;                          // a peer's line never arrived: this column's sum is not valid
   const long long t0 = wall_clock64();
   // once a peer has been declared lost nobody waits again: one bounded stall, then the host sees the error code
   if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timeout_ticks = 0;
@@ -79,12 +80,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
     const xg_line_t* src = px.box[me] + (size_t)(par * nr + r) * px.Rp + c;
     xg_line_t line = xg_load(src);
     while (line.y != seq || line.w != seq) {
-      if (wall_clock64() - t0 > timeout_ticks) { atomicExch(err, 1); break; }
+      if (wall_clock64() - t0 > timeout_ticks) { atomicExch(err, 1); lost = true; break; }
       __builtin_amdgcn_s_sleep(1);
       line = xg_load(src);
     }
     tot += __longlong_as_double((long long)(((unsigned long long)line.z << 32) | line.x));
   }
+  if (lost) return;                           // leave gl, the weights and the Adam moments untouched; the host
+                                              // sees err at its next synchronisation (xg_check) and raises
   gl[c] = tot;
   if (ADAM) {
     if (c < n) {

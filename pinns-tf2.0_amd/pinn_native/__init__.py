@@ -98,6 +98,7 @@ _SIGNATURES = {
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
+    "pinn_residual_at": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_comm_xgmi_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
     "pinn_comm_xgmi_attach": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, _c_int_p]),
     "pinn_comm_xgmi_selftest": (ctypes.c_int, [ctypes.c_void_p, _c_int_p]),
@@ -309,6 +310,13 @@ class Engine(object):
         n = self.n_u if self.pde == "burgers_ide" else self.n_f
         f = np.empty((n, self.n_out), dtype=np.float64)
         self._check(self._lib.pinn_residual(self._h, _dp(f), n))
+        return f
+
+    def residual_at(self, X):
+        """f_model at arbitrary points X [n, 2] -> [n, n_out]"""
+        X = _f64(X).reshape(-1, 2)
+        f = np.empty((X.shape[0], self.n_out), dtype=np.float64)
+        self._check(self._lib.pinn_residual_at(self._h, _dp(X), X.shape[0], _dp(f)))
         return f
 
     # ---- optimisers ------------------------------------------------------------------------

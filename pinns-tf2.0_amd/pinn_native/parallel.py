@@ -39,12 +39,14 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
     """Create the communicator of `engine`.
 
     RCCL: rank 0 draws the unique id, torch.distributed (any backend; gloo in this repo) broadcasts it, every
-    rank joins.  Then, unless mailbox=False (default: on unless PINN_COMM=rccl), the peer-mapped mailbox
-    all-reduce of csrc/kernels_xgmi.h is set up on top: handles are all-gathered, every rank attaches and
-    self-tests, and the mailboxes are switched on only if *every* rank reports success -- otherwise all ranks
-    stay on RCCL.  Returns the mode in use ("rccl" or "mailbox")."""
+    rank joins.  That is the default and what north_star names.  With PINN_COMM=auto (opt-in: the mailboxes have
+    only ever run between processes sharing ONE device, never across an xGMI link) or mailbox=True, the
+    peer-mapped mailbox all-reduce of csrc/kernels_xgmi.h is set up on top: handles are all-gathered, every rank
+    attaches and self-tests, both implementations are timed on the node, and the mailboxes are switched on only
+    if *every* rank reports success and they are not slower -- otherwise all ranks stay on RCCL.
+    Returns the mode in use ("rccl" or "mailbox")."""
     from . import Engine, PinnNativeError
-    policy = os.environ.get("PINN_COMM", "auto").lower()     # auto | rccl | mailbox-only (no RCCL communicator)
+    policy = os.environ.get("PINN_COMM", "rccl").lower()     # rccl (default) | auto | mailbox-only (no RCCL communicator)
     if policy == "mailbox-only":
         rccl, mailbox = False, True
     if rccl:

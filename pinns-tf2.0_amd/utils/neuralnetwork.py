@@ -11,11 +11,14 @@ return shapes (numpy arrays where the reference returns eager tensors).
 What changes: there is no TensorFlow, so a subclass cannot spell its PDE with GradientTapes.
 It names one of the engine's residual kinds instead (`pde="burgers" | "burgers_ide" |
 "schrodinger" | "burgers_disc" | "burgers_disc_ide"`) and the engine evaluates forward, u_t/u_x/u_xx, residual, loss and the flat
-gradient on the GPU (csrc/).  Extra, optional hp keys: "dtype" ("f32" default | "f64") for
-the kernel arithmetic, "device" (HIP ordinal).  Host interchange stays float64.
+gradient on the GPU (csrc/).  Extra, optional hp keys: "dtype" ("f64" default = the reference's
+arithmetic, neuralnetwork.py:24-26 | "f32" = the throughput mode north_star sanctions) for the
+kernel arithmetic, "device" (HIP ordinal).  Host interchange stays float64.
 
 There is no CPU path: constructing a NeuralNetwork without the HIP library or a GPU raises.
 """
+import hashlib
+
 import numpy as np
 
 from custom_lbfgs import lbfgs, Struct
@@ -86,8 +89,9 @@ def _as_points(X, owner):
         return X.reshape(-1, 1)
     if X.shape[1] == 1:
         # Schrodinger driver quirk (inf_cont_schrodinger.py:164): x0 of shape [N,1] is handed
-        # to a 2-input network.  Default: the evident intent (x0, t=0); hp["compat_x0_broadcast"]
-        # reproduces what broadcasting against lb/ub does, i.e. (x0, x0).
+        # to a 2-input network.  Default = what the reference computes: the Lambda layer broadcasts
+        # [N,1] against lb/ub [2] (neuralnetwork.py:29-30), i.e. the network sees (x0, x0).
+        # hp["compat_x0_broadcast"] = false switches to the evident intent (x0, t=0) = prep_data's X0.
         second = X if owner._compat_x0 else np.zeros_like(X)
         X = np.concatenate([X, second], axis=1)
     return X
@@ -111,8 +115,8 @@ class NeuralNetwork(object):
         self.tf_optimizer = _AdamConfig(hp["tf_lr"], hp["tf_b1"], hp["tf_eps"])
 
         self.dtype = "float64"                       # host interchange dtype
-        self.compute_dtype = hp.get("dtype", "f32")  # kernel arithmetic
-        self._compat_x0 = bool(hp.get("compat_x0_broadcast", False))
+        self.compute_dtype = hp.get("dtype", "f64")  # kernel arithmetic; the reference is float64 (:24-26)
+        self._compat_x0 = bool(hp.get("compat_x0_broadcast", True))
         self.layers = [int(v) for v in layers]
         self.ub = np.asarray(ub, dtype=np.float64)
         self.lb = np.asarray(lb, dtype=np.float64)
@@ -172,8 +176,10 @@ class NeuralNetwork(object):
     def _bind(self, X, u):
         X = _as_points(X, self)
         u = np.asarray(u, dtype=np.float64).reshape(X.shape[0], -1)
-        key = (X.shape, u.shape, X.tobytes(), u.tobytes()) if X.shape[0] <= 4096 else \
-            (X.shape, u.shape, float(X.sum()), float(u.sum()), X[:4].tobytes(), X[-4:].tobytes())
+        h = hashlib.blake2b(digest_size=16)          # full-buffer digest: a few ms at 1e6 points
+        h.update(np.ascontiguousarray(X).tobytes())
+        h.update(np.ascontiguousarray(u).tobytes())
+        key = (X.shape, u.shape, h.digest())
         if key != self._bound:
             self._engine.set_data(X, u)
             self._bound = key
@@ -227,6 +233,7 @@ class NeuralNetwork(object):
         self._bind(X, u)
 
         def loss_and_flat_grad(w):
+            self._bind(X, u)             # the closure evaluates ITS data, whatever was bound in between
             self.set_weights(w)
             loss_value, flat, _ = self._engine.loss_grad()
             return loss_value, flat

@@ -51,3 +51,33 @@ def schrodinger_sets():
             cache[key] = schrodingerutil.prep_data(NLS_MAT, N_0, N_b, N_f, noise=0.0)
         return cache[key]
     return get
+
+
+_MEASURED = os.path.join(ROOT, "gpurun_out", "parity_measured.jsonl")
+
+
+@pytest.fixture
+def record(request):
+    """record(name=value, ...): appends the deviations a GPU parity test measured to gpurun_out/parity_measured.jsonl
+    (scratch; a copy of the last full run is committed under profiles/), next to asserting them."""
+    import json
+
+    def rec(**kw):
+        try:
+            os.makedirs(os.path.dirname(_MEASURED), exist_ok=True)
+            with open(_MEASURED, "a") as fh:
+                fh.write(json.dumps({"test": request.node.name, **{k: (float(v) if hasattr(v, "__float__") else v)
+                                                                    for k, v in kw.items()}}) + "\n")
+        except OSError:
+            pass
+    return rec
+
+
+def ensemble_accepts(errors, value):
+    """Acceptance rule for a final error of a roundoff-chaotic schedule, given the reference's own ensemble `errors`
+    (final errors of reference runs whose initial weights differ by a few ulp): the value may be no further from
+    the ensemble's median than the ensemble's own most distant member.  -> (ok, median, radius)"""
+    e = np.sort(np.asarray(errors, dtype=np.float64))
+    med = float(np.median(e))
+    radius = float(np.max(np.abs(e - med)))
+    return abs(value - med) <= radius, med, radius

@@ -19,10 +19,9 @@ What each fixture pins, and from which reference code:
   burgers_default_run.json  stdout of the unmodified script with default hp
   schrodinger_eval.npz   SchrodingerInformedNN.loss at the canonical init (compat x0 broadcast)
   logger_bytes.json      utils/logger.py output format
-  burgers_ide_eval.npz   identification variant: the reference file does not parse
-                         (ide_cont_burgers.py, SyntaxError), so this one is produced by a
-                         torch nested-autograd restatement of its evident intent, written
-                         here (not reference code) and flagged as such in the fixture.
+  burgers_ide_eval.npz   identification variant (1d-burgers/ide_cont_burgers.py:47-172): the file does not
+  burgers_ide_run.json   parse as shipped (IndentationError line 31); repair_ide_cont.py re-indents it --
+                         whitespace only, checked -- and the repaired module runs unmodified over the shims
   burgers_disc_eval*.npz      discrete-time inference: BurgersInformedNN.U_0_model / loss /
                          get_loss_and_flat_grad / predict of 1d-burgers/inf_disc_burgers.py:57-129 and the
                          prep_data branch burgersutil.py:43-61, script run unmodified
@@ -271,6 +270,30 @@ def gen_schrodinger_eval():
             tag, res["loss_compat"], res["loss_intent"]))
 
 
+def gen_schrodinger_run():
+    """stdout of the unmodified script for 10 Adam epochs (lr .05, b1 .99, eps .1 -- inf_cont_schrodinger.py:23-41):
+    the progress lines and the per-evaluation `mse_0 / mse_b / mse_f` print of loss() (:128), plus the final error
+    on |h| (:155-158).  The driver call is the reference's own fit(x0 [N0,1], ...) (:164), i.e. the x0-broadcast
+    reading."""
+    hp = {"N_0": 50, "N_b": 50, "N_f": 20000, "layers": [2, 100, 100, 100, 100, 2],
+          "tf_epochs": 10, "tf_lr": 0.05, "tf_b1": 0.99, "tf_eps": 1e-1,
+          "nt_epochs": 0, "nt_lr": 1.2, "nt_ncorr": 50, "log_frequency": 1}
+    sys.path.insert(0, "1dcomplex-schrodinger")
+    g, out = run_reference_script("1dcomplex-schrodinger/inf_cont_schrodinger.py", hp)
+    mse = []
+    for l in out.splitlines():
+        if l.startswith("mse_0"):
+            t = l.split()
+            mse.append([float(t[1]), float(t[3]), float(t[5])])
+    rec = {"hp": hp, "lines": [l for l in out.splitlines() if l.startswith(("tf_epoch", "Training finished"))],
+           "mse_0_b_f": mse, "final_error": float(g["error"]()),
+           "w_final_sha": sha16(g["pinn"].get_weights().numpy())}
+    np.save(os.path.join(HERE, "schrodinger_run_w_final.npy"), g["pinn"].get_weights().numpy().astype(np.float32))
+    with open(os.path.join(HERE, "schrodinger_run.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("schrodinger run: %d mse lines, final error %.6e" % (len(mse), rec["final_error"]))
+
+
 def gen_logger_bytes():
     from logger import Logger
     hp = {"log_frequency": 10, "N_f": 3}
@@ -290,59 +313,89 @@ def gen_logger_bytes():
     print("logger_bytes ok")
 
 
-def gen_burgers_ide_eval():
-    """NOT reference code: torch nested-autograd restatement of ide_cont_burgers.py:52-118
-    (the file itself has a SyntaxError).  Mirrors the tape structure: u=model(X); u_x inside
-    the tape; u_xx, u_t outside; f = u_t + l1*u*u_x - exp(l2)*u_xx evaluated at the data points."""
-    import torch
-    import burgersutil
-    from scipy.stats import truncnorm
-    for tag, N_u in (("", 10000), ("_small", 1500)):
-        np.random.seed(1234)
-        r = burgersutil.prep_data("1d-burgers/data/burgers_shock.mat", N_u, noise=0.0)
-        X_u, u, ub, lb = r[7], r[8], r[9], r[10]
-        layers = [2, 20, 20, 20, 20, 20, 20, 20, 20, 1]
-        rs = np.random.RandomState(1234)
-        Ws, bs = [], []
-        for fi, fo in zip(layers[:-1], layers[1:]):
-            std = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
-            Ws.append(torch.tensor(truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * std,
-                                   requires_grad=True))
-            bs.append(torch.zeros(fo, dtype=torch.float64, requires_grad=True))
-        l1 = torch.tensor([0.3], dtype=torch.float64, requires_grad=True)   # off the 0 init so dL/dl1 != trivial
-        l2 = torch.tensor([-6.0], dtype=torch.float64, requires_grad=True)
-        x = torch.tensor(X_u[:, 0:1], requires_grad=True)
-        t = torch.tensor(X_u[:, 1:2], requires_grad=True)
-        lbt, ubt = torch.tensor(lb), torch.tensor(ub)
+def _run_repaired_ide(hp):
+    """ide_cont_burgers.py does not parse as shipped (IndentationError line 31); repair_ide_cont.py re-indents it
+    (whitespace only, proven by its check()) into a scratch file which is then run unmodified over the shims."""
+    import repair_ide_cont
+    dst = repair_ide_cont.write("/tmp/_golden_ide/1d-burgers/ide_cont_burgers.py")
+    return run_reference_script(dst, hp)
 
-        def model(X):
-            h = 2.0 * (X - lbt) / (ubt - lbt) - 1.0
-            for i, (W, b) in enumerate(zip(Ws, bs)):
-                h = h @ W + b
-                if i < len(Ws) - 1:
-                    h = torch.tanh(h)
-            return h
-        uu = model(torch.cat([x, t], 1))
-        ones = torch.ones_like(uu)
-        u_x = torch.autograd.grad(uu, x, ones, create_graph=True)[0]
-        u_xx = torch.autograd.grad(u_x, x, ones, create_graph=True)[0]
-        u_t = torch.autograd.grad(uu, t, ones, create_graph=True)[0]
-        f = u_t + l1 * uu * u_x - torch.exp(l2) * u_xx
-        ut = torch.tensor(u)
-        loss = torch.mean((ut - model(torch.tensor(X_u))) ** 2) + torch.mean(f ** 2)
-        params = []
-        for W, b in zip(Ws, bs):
-            params += [W, b]
-        params += [l1, l2]
-        grads = torch.autograd.grad(loss, params)
-        flat_w = np.concatenate([p.detach().numpy().ravel() for p in params])
-        flat_g = np.concatenate([gg.numpy().ravel() for gg in grads])
-        np.savez_compressed(os.path.join(HERE, "burgers_ide_eval%s.npz" % tag),
-                            N_u=N_u, w0=flat_w, loss=float(loss), grad=flat_g,
-                            f_first=f.detach().numpy()[:64, 0], sha_X_u=sha16(X_u),
-                            source="torch restatement (reference file has SyntaxError)")
-        print("burgers_ide_eval%s: loss=%.17g dl1=%.6e dl2=%.6e" % (
-            tag, float(loss), flat_g[-2], flat_g[-1]))
+
+def ide_hp(**kw):
+    hp = {"N_u": 2000, "layers": [2, 20, 20, 20, 20, 20, 20, 20, 20, 1], "tf_epochs": 0, "tf_lr": 0.001,
+          "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 0, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 10}
+    hp.update(kw)
+    return hp
+
+
+def gen_burgers_ide_eval():
+    """Identification pinned to the reference's own code: BurgersInformedNN.f_model / loss /
+    wrap_training_variables / get_weights / set_weights / get_params / fit / predict of
+    1d-burgers/ide_cont_burgers.py:47-172 and the prep_data branch burgersutil.py:63-75,99-102, run over the shims
+    after the whitespace-only repair.  The model evaluated is the script's second one (its "noise" rerun, :200-205:
+    a fresh sample from the continuing numpy stream, weights from the continuing initialiser stream)."""
+    import tensorflow as tf
+    from custom_lbfgs import lbfgs, Struct
+    for tag, N_u in (("", 10000), ("_small", 1500)):
+        hp = ide_hp(N_u=N_u)
+        g, _ = _run_repaired_ide(hp)
+        pinn, X_u, u, X_star = g["pinn"], g["X_u_train"], g["u_train"], g["X_star"]
+        w_init = pinn.get_weights().numpy()
+        w0 = w_init.copy()
+        w0[-2:] = [0.3, -5.0]                  # off the (0, -6) initial values so every lambda term is live
+        Xt, ut = pinn.tensor(X_u), pinn.tensor(u)
+        closure = pinn.get_loss_and_flat_grad(Xt, ut)
+        loss, grad = closure(tf.convert_to_tensor(w0))
+        f = pinn.f_model(pinn.X_u).numpy()
+        u_pred, f_star = pinn.predict(X_star)
+        l1, l2 = pinn.get_params(numpy=True)
+        # ---- Adam trajectory (10 steps from w0, lr 1e-3 as the script) ----
+        pinn.set_weights(tf.convert_to_tensor(w0))
+        losses, snaps = [], {}
+        for it in range(10):
+            losses.append(float(pinn.tf_optimization_step(Xt, ut)))
+            if it + 1 in (1, 10):
+                snaps["adam_w_after_%d" % (it + 1)] = pinn.get_weights().numpy()
+        # ---- L-BFGS trajectory (25 iterations from w0, reference driver) ----
+        pinn.set_weights(tf.convert_to_tensor(w0))
+        cfg = Struct()
+        cfg.learningRate = hp["nt_lr"]
+        cfg.maxIter = 25
+        cfg.nCorrection = 6
+        cfg.tolFun = 1.0 * np.finfo(float).eps
+        logs = []
+        x_ret, f_hist, n_eval = lbfgs(closure, pinn.get_weights(), cfg, Struct(), True,
+                                      lambda it, fv, is_iter: logs.append((int(it), float(fv))))
+        np.savez_compressed(
+            os.path.join(HERE, "burgers_ide_eval%s.npz" % tag), hp=json.dumps(hp),
+            N_u=N_u, w_init=w_init, w0=w0, loss=float(loss), grad=grad.numpy(), f_first=f[:64, 0], f_sha=sha16(f),
+            X_u=X_u, u=u, sha_X_u=sha16(X_u), params=np.array([l1, l2]),
+            u_pred_stride=u_pred[::257, 0], f_star_stride=f_star[::257, 0],
+            adam_losses=np.array(losses), lbfgs_max_iter=25, lbfgs_n_corr=6,
+            lbfgs_log_iters=np.array([l[0] for l in logs]), lbfgs_log_losses=np.array([l[1] for l in logs]),
+            lbfgs_f_hist=np.array([float(v) for v in f_hist]), lbfgs_n_eval=int(n_eval),
+            lbfgs_x_returned=x_ret.numpy(), lbfgs_w_model=pinn.get_weights().numpy(),
+            source="reference ide_cont_burgers.py (whitespace-only repair, tests/golden/repair_ide_cont.py) over the shims",
+            **snaps)
+        print("burgers_ide_eval%s: loss=%.17g dl1=%.6e dl2=%.6e adam[9]=%.10e lbfgs[-1]=%.10e" % (
+            tag, float(loss), grad.numpy()[-2], grad.numpy()[-1], losses[-1], float(f_hist[-1])))
+
+
+def gen_burgers_ide_run():
+    """stdout of the repaired script: 100 Adam + 100 L-BFGS (the default 500 cut to 100 to keep the fixture
+    inside the range where two float64 implementations still agree), both models, and the printed lambdas."""
+    hp = ide_hp(tf_epochs=100, nt_epochs=100)
+    g, out = _run_repaired_ide(hp)
+    keep = ("tf_epoch", "nt_epoch", "Training finished", "l1", "l2", "--")
+    rec = {"hp": hp, "lines": [l for l in out.splitlines() if l.startswith(keep)],
+           "lambda_1": float(g["lambda_1_pred"]), "lambda_2": float(g["lambda_2_pred"]),
+           "lambda_1_noise": float(g["lambda_1_pred_noise"]), "lambda_2_noise": float(g["lambda_2_pred_noise"]),
+           "u_pred_stride": np.asarray(g["u_pred"])[::257, 0].tolist(),
+           "f_pred_stride": np.asarray(g["f_pred"])[::257, 0].tolist()}
+    with open(os.path.join(HERE, "burgers_ide_run.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("ide run: l1 %.6e l2 %.6e | noise l1 %.6e l2 %.6e" % (
+        rec["lambda_1"], rec["lambda_2"], rec["lambda_1_noise"], rec["lambda_2_noise"]))
 
 
 def _install_disc_adapters():
@@ -477,6 +530,7 @@ def gen_disc_runs():
 def main():
     os.chdir(REF)
     sys.path.insert(0, SHIMS)
+    sys.path.append(HERE)
     sys.path.insert(1, os.path.join(REF, "utils"))
     sys.path.insert(2, os.path.join(REF, "1d-burgers"))
     sys.path.insert(3, os.path.join(REF, "1dcomplex-schrodinger"))
@@ -492,8 +546,11 @@ def main():
         gen_burgers_eval_adam_lbfgs()
     if "ide" in which:
         gen_burgers_ide_eval()
+        gen_burgers_ide_run()
     if "schrodinger" in which:
         gen_schrodinger_eval()
+    if "schrodinger_run" in which or not sys.argv[1:]:
+        gen_schrodinger_run()
     if "default" in which:
         gen_default_run()
     if "disc" in which:

@@ -201,6 +201,9 @@ class _Lambda(object):
 
 
 _GLOROT_RS = [None]
+# sensitivity studies (tests/golden/make_band.py): every initial kernel is multiplied by this factor, e.g.
+# 1 + k * 2**-52 = a k-ulp relative perturbation of the initial weights.  1.0 (exact) by default.
+_INIT_SCALE = [1.0]
 
 
 def _glorot_rs():
@@ -221,6 +224,8 @@ class _Dense(object):
         rs = _glorot_rs()
         std = math.sqrt(2.0 / (fan_in + self.units)) / 0.87962566103423978
         w = truncnorm.rvs(-2, 2, size=(fan_in, self.units), random_state=rs) * std
+        if _INIT_SCALE[0] != 1.0:
+            w = w * _INIT_SCALE[0]
         self.W = T(torch.tensor(w, requires_grad=True))
         self.b = T(torch.zeros(self.units, requires_grad=True))
 

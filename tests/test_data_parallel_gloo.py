@@ -113,7 +113,10 @@ def _comm_worker(rank, world, port, out_dir, scenario):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    os.environ.pop("PINN_COMM", None)
+    if scenario.get("policy"):
+        os.environ["PINN_COMM"] = scenario["policy"]
+    else:
+        os.environ.pop("PINN_COMM", None)                  # default policy = RCCL (north_star), mailboxes opt-in
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import pinn_native
     from pinn_native import parallel
@@ -127,18 +130,74 @@ def _comm_worker(rank, world, port, out_dir, scenario):
 
 
 @pytest.mark.parametrize("scenario,expect", [
-    ({}, "mailbox"),                                   # everything works, mailboxes faster -> mailboxes everywhere
-    ({"mailbox_us": 50.0}, "rccl"),                    # ... but slower on this node -> RCCL everywhere
-    ({"export": 1}, "rccl"),                           # one rank cannot export -> nobody attaches
-    ({"unmapped": 0}, "rccl"),                         # one rank cannot map a peer -> nobody runs the self-test
-    ({"bad_selftest": 1}, "rccl"),                     # one rank's self-test fails -> RCCL everywhere
+    ({}, "rccl"),                                      # default policy: RCCL, the mailboxes are never touched
+    ({"policy": "auto"}, "mailbox"),                   # opt-in; everything works, mailboxes faster -> mailboxes everywhere
+    ({"policy": "auto", "mailbox_us": 50.0}, "rccl"),  # ... but slower on this node -> RCCL everywhere
+    ({"policy": "auto", "export": 1}, "rccl"),         # one rank cannot export -> nobody attaches
+    ({"policy": "auto", "unmapped": 0}, "rccl"),       # one rank cannot map a peer -> nobody runs the self-test
+    ({"policy": "auto", "bad_selftest": 1}, "rccl"),   # one rank's self-test fails -> RCCL everywhere
 ])
 def test_comm_setup_is_unanimous(tmp_path, scenario, expect):
     port = 29600 + (os.getpid() + len(str(scenario))) % 300
     mp.spawn(_comm_worker, args=(2, port, str(tmp_path), scenario), nprocs=2, join=True)
     outs = [open(tmp_path / ("rank%d.txt" % r)).read().split("|") for r in range(2)]
     assert outs[0][0] == outs[1][0] == expect and outs[0][1] == outs[1][1] == expect, outs
+    if "policy" not in scenario:
+        assert all("export" not in o[2] and "attach" not in o[2] for o in outs)
     if "unmapped" in scenario:
         assert all("selftest" not in o[2] for o in outs)
     if "export" in scenario:
         assert all("attach" not in o[2] for o in outs)
+
+
+# ---- bench.py's timing contract (world_size 2 over gloo, scripted engine) ------------------------------------------
+class _SleepyEngine(object):
+    """stands in for pinn_native.Engine in bench.time_blocks: a 'step' costs a rank-dependent sleep"""
+
+    def __init__(self, rank):
+        self.dt = 0.004 if rank == 0 else 0.010
+        self.steps = 0
+
+    def set_weights(self, w): pass
+    def adam_init(self, *a): pass
+    def sync(self): pass
+
+    def adam_run(self, n, want_losses=True):
+        import time
+        time.sleep(self.dt * n)
+        self.steps += n
+
+    def lbfgs_begin(self, n, *a): self.left = n
+
+    def lbfgs_run(self, n):
+        import time
+        time.sleep(self.dt * self.left)
+        self.steps += self.left
+        return [], [], 1
+
+
+def _bench_worker(rank, world, port, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    eng = _SleepyEngine(rank)
+    times, done = bench.time_blocks(eng, bench.World(dist, world, rank), None, 1, 2, min_ms=100.0)
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d|%d|%s" % (done, eng.steps, ",".join("%.6f" % t for t in times)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_blocks_are_max_over_ranks_and_identical_everywhere(tmp_path):
+    """every block is exactly K steps, its time is the MAX over ranks (the slow rank sleeps 10 ms per step), every rank
+    sees the same list and therefore runs the same number of blocks, and blocks repeat until >= min_ms are timed"""
+    port = 29700 + os.getpid() % 200
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    outs = [open(tmp_path / ("rank%d.txt" % r)).read().split("|") for r in range(2)]
+    assert outs[0][2] == outs[1][2] and outs[0][0] == outs[1][0] == "1"
+    times = [float(t) for t in outs[0][2].split(",")]
+    assert all(t >= 3 * 0.010 for t in times)                    # 3 steps of the slow rank
+    assert sum(times) >= 0.100 and sum(times[:-1]) < 0.100       # stops once >= 100 ms are timed
+    assert int(outs[0][1]) == int(outs[1][1]) == 3 * len(times)  # exactly K steps per block on every rank

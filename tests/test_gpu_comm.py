@@ -89,7 +89,7 @@ def test_auto_policy_probes_both_implementations(burgers_sets, monkeypatch):
         def all_gather_object(out, obj):
             out[0] = obj
 
-    monkeypatch.delenv("PINN_COMM", raising=False)
+    monkeypatch.setenv("PINN_COMM", "auto")              # opt-in; the default policy is RCCL
     eng, X_f, X_u, u = _engine(burgers_sets, "f32")
     eng.set_collocation(X_f); eng.set_data(X_u, u)
     g = np.load(golden("burgers_eval_small.npz"))

@@ -17,6 +17,11 @@ NU = 0.01 / np.pi
 TOL = {"f64": dict(loss=1e-12, grad=1e-11), "f32": dict(loss=1e-5, grad=2e-5)}
 
 
+# float32-kernel trajectory bounds (relative; measured on MI355X, profiles/r02_parity_measured.jsonl, x3 margin)
+F32_ADAM_TOL = dict(w1=1e-3, w5=5e-3, loss5=2e-2, loss10=5e-2, loss30=2e-1)
+F32_LBFGS_TOL = dict(loss5=1e-3, loss10=1e-2, loss25=1e-1)
+
+
 def rel(a, b):
     return np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(np.max(np.abs(b)), 1e-300)
 
@@ -113,7 +118,7 @@ def test_burgers_predict(burgers_sets, dtype):
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
-def test_burgers_adam_trajectory(burgers_sets, dtype, tag, N_u, N_f):
+def test_burgers_adam_trajectory(burgers_sets, record, dtype, tag, N_u, N_f):
     g = np.load(golden("burgers_eval%s.npz" % tag))
     ga = np.load(golden("burgers_adam%s.npz" % tag))
     hp = json.loads(str(ga["hp"]))
@@ -132,10 +137,17 @@ def test_burgers_adam_trajectory(burgers_sets, dtype, tag, N_u, N_f):
         assert np.max(np.abs(losses - ga["losses"]) / ga["losses"]) < 1e-8
         assert rel(eng.get_weights(), ga["w_after_30"]) < 1e-7
     else:
-        # Adam's m/(sqrt(v)+eps) turns f32 gradient roundoff into O(lr*1e-4) weight differences
-        # on the first step; the trajectory stays close over 30 steps
-        assert rel(w1, ga["w_after_1"]) < 1e-3
-        assert np.max(np.abs(losses[:5] - ga["losses"][:5]) / ga["losses"][:5]) < 2e-2
+        # float32 kernels, float64 optimiser state.  Adam's m/(sqrt(v)+eps) turns the 1e-7 relative gradient
+        # roundoff of the first step into an O(lr * 1e-4) weight difference; lr = 0.03 then amplifies it (the
+        # schedule is the chaotic one, see test_gpu_end_to_end.py), so the bound widens with the step count.
+        dl = np.abs(losses - ga["losses"]) / ga["losses"]
+        record(dtype=dtype, tag=tag, w1=rel(w1, ga["w_after_1"]), w5=rel(w5, ga["w_after_5"]),
+               w30=rel(eng.get_weights(), ga["w_after_30"]), loss_dev_5=float(dl[:5].max()),
+               loss_dev_10=float(dl[:10].max()), loss_dev_30=float(dl.max()))
+        assert rel(w1, ga["w_after_1"]) < F32_ADAM_TOL["w1"]
+        assert rel(w5, ga["w_after_5"]) < F32_ADAM_TOL["w5"]
+        assert dl[:5].max() < F32_ADAM_TOL["loss5"] and dl[:10].max() < F32_ADAM_TOL["loss10"]
+        assert dl.max() < F32_ADAM_TOL["loss30"]
     eng.close()
 
 
@@ -163,21 +175,54 @@ def test_burgers_lbfgs_trajectory_f64(burgers_sets, tag, N_u, N_f, mode):
     eng.close()
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("tag", ["_small", ""])
-def test_burgers_ide_eval(dtype, tag):
-    import burgersutil
-    from conftest import BURGERS_MAT
-    from oracle import pde
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
+def test_burgers_lbfgs_trajectory_f32(burgers_sets, record, tag, N_u, N_f, mode):
+    """the headline metric is 2/3 float32 L-BFGS iterations: the float32 kernels (float64 optimiser state) follow
+    the reference's own 25-iteration L-BFGS trajectory (custom_lbfgs.py:39-236 driven by the PINN closure) to the
+    stated prefix bounds, same log iterations, same last-iteration quirk"""
+    g = np.load(golden("burgers_eval%s.npz" % tag))
+    gl = np.load(golden("burgers_lbfgs%s.npz" % tag))
+    eng, *_ = make_burgers(burgers_sets, N_u, N_f, "f32")
+    eng.lbfgs_set_mode(mode)
+    eng.set_weights(g["w0"])
+    eng.lbfgs_begin(int(gl["max_iter"]), float(gl["lr"]), int(gl["n_corr"]), np.finfo(float).eps)
+    it_all, lo_all, done = [], [], 0
+    while not done:
+        it, lo, done = eng.lbfgs_run(7)
+        it_all.extend(it.tolist())
+        lo_all.extend(lo.tolist())
+    assert done == 1 and it_all == gl["log_iters"].tolist()
+    dl = np.abs(np.array(lo_all) - gl["log_losses"]) / gl["log_losses"]
+    record(tag=tag, mode=mode, loss_dev_5=float(dl[:5].max()), loss_dev_10=float(dl[:10].max()),
+           loss_dev_25=float(dl.max()), w_model=rel(eng.get_weights(), gl["w_model"]),
+           x_returned=rel(eng.lbfgs_x(), gl["x_returned"]))
+    assert dl[:5].max() < F32_LBFGS_TOL["loss5"] and dl[:10].max() < F32_LBFGS_TOL["loss10"]
+    assert dl.max() < F32_LBFGS_TOL["loss25"]
+    assert not np.allclose(eng.get_weights(), eng.lbfgs_x())
+    eng.close()
+
+
+def _ide_engine(g, dtype):
     from pinn_native import Engine
-    g = np.load(golden("burgers_ide_eval%s.npz" % tag))
-    np.random.seed(1234)
-    r = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.0)
-    X_u, u, ub, lb = r[7], r[8], r[9], r[10]
     layers = [2] + [20] * 8 + [1]
+    lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
     eng = Engine(layers, lb, ub, pde="burgers_ide", dtype=dtype)
     assert eng.n_params == 3023
-    eng.set_data(X_u, u)
+    eng.set_data(g["X_u"], g["u"])
+    return eng, layers, lb, ub
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_burgers_ide_eval(burgers_sets, record, dtype, tag):
+    """identification against the reference's own ide_cont_burgers.py (whitespace-repaired, run
+    over the shims by make_golden.py): loss, flat gradient incl. lambda_1 / lambda_2, f_model at the data points,
+    predict = (u, f) at X_star (:169-172)"""
+    from oracle import pde
+    g = np.load(golden("burgers_ide_eval%s.npz" % tag))
+    assert "reference ide_cont_burgers.py" in str(g["source"])
+    eng, layers, lb, ub = _ide_engine(g, dtype)
     eng.set_weights(g["w0"])
     loss, grad, _ = eng.loss_grad()
     tol = TOL[dtype]
@@ -185,8 +230,47 @@ def test_burgers_ide_eval(dtype, tag):
     assert rel(grad[:-2], g["grad"][:-2]) < tol["grad"]
     assert abs(grad[-2] - g["grad"][-2]) < tol["grad"] * abs(g["grad"][-2]) * 50
     assert abs(grad[-1] - g["grad"][-1]) < tol["grad"] * abs(g["grad"][-1]) * 50
-    lo, go, ex = pde.burgers_ide_loss_grad(g["w0"], layers, lb, ub, X_u, u)
-    assert rel(eng.residual(), ex["f"]) < tol["grad"] * 10
+    f = eng.residual()
+    assert np.max(np.abs(f[:64, 0] - g["f_first"])) < tol["grad"] * 10
+    lo, go, ex = pde.burgers_ide_loss_grad(g["w0"], layers, lb, ub, g["X_u"], g["u"])
+    assert rel(f, ex["f"]) < tol["grad"] * 10
+    X_star = burgers_sets(100, 10000)[5]
+    up, fs = eng.predict(X_star), eng.residual_at(X_star)
+    du, df = np.max(np.abs(up[::257, 0] - g["u_pred_stride"])), np.max(np.abs(fs[::257, 0] - g["f_star_stride"]))
+    record(dtype=dtype, tag=tag, u_star_maxabs=du, f_star_maxabs=df)
+    assert du < (1e-12 if dtype == "f64" else 2e-6) and df < (1e-10 if dtype == "f64" else 2e-4)
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["_small", ""])
+def test_burgers_ide_adam_and_lbfgs_trajectories_f64(record, tag):
+    """10 Adam steps (lr 1e-3, ide_cont_burgers.py:36-39) and the 25-iteration L-BFGS trajectory of the reference's
+    identification model, float64: 1e-8 on the losses"""
+    g = np.load(golden("burgers_ide_eval%s.npz" % tag))
+    eng, *_ = _ide_engine(g, "f64")
+    eng.set_weights(g["w0"])
+    eng.adam_init(1e-3, 0.9, 0.999, 1e-7)
+    l1 = eng.adam_run(1)
+    w1 = eng.get_weights()
+    l9 = eng.adam_run(9)
+    losses = np.concatenate([l1, l9])
+    da = float(np.max(np.abs(losses - g["adam_losses"]) / g["adam_losses"]))
+    assert rel(w1, g["adam_w_after_1"]) < 1e-12
+    assert da < 1e-8 and rel(eng.get_weights(), g["adam_w_after_10"]) < 1e-8
+    for mode in (0, 1):
+        eng.lbfgs_set_mode(mode)
+        eng.set_weights(g["w0"])
+        eng.lbfgs_begin(int(g["lbfgs_max_iter"]), 0.8, int(g["lbfgs_n_corr"]), np.finfo(float).eps)
+        it_all, lo_all, done = [], [], 0
+        while not done:
+            it, lo, done = eng.lbfgs_run(6)
+            it_all.extend(it.tolist())
+            lo_all.extend(lo.tolist())
+        assert done == 1 and it_all == g["lbfgs_log_iters"].tolist()
+        dl = float(np.max(np.abs(np.array(lo_all) - g["lbfgs_log_losses"]) / g["lbfgs_log_losses"]))
+        dwm, dx = rel(eng.get_weights(), g["lbfgs_w_model"]), rel(eng.lbfgs_x(), g["lbfgs_x_returned"])
+        record(tag=tag, mode=mode, adam_loss_dev=da, lbfgs_loss_dev=dl, w_model=dwm, x_returned=dx)
+        assert dl < 1e-8 and dwm < 1e-6 and dx < 1e-6
     eng.close()
 
 
@@ -219,6 +303,69 @@ def test_schrodinger_eval(schrodinger_sets, dtype, tag, N_f):
     assert np.max(np.abs(uv[::517, 0] - g["u_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
     assert np.max(np.abs(uv[::517, 1] - g["v_pred_stride"])) < (1e-12 if dtype == "f64" else 5e-6)
     eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,N_f", [("_small", 1024), ("", 20000)])
+def test_schrodinger_adam_trajectory_and_loss_parts(schrodinger_sets, record, dtype, tag, N_f):
+    """5 Adam steps in the Schrodinger regime (lr .05, beta_1 .99, eps .1 -- inf_cont_schrodinger.py:23-41) from the
+    reference's own run (fixture fields adam_losses_compat, w_after_5: the script's fit(x0 [N0,1], ...) call, :164,
+    i.e. the x0-broadcast reading), through pinn_adam_run_terms: losses, weights, and that the three parts add up"""
+    from pinn_native import Engine
+    g = np.load(golden("schrodinger_eval%s.npz" % tag))
+    hp = json.loads(str(g["hp"]))
+    r = schrodinger_sets(50, 50, N_f)
+    X_f, ub, lb, tb, x0, u0, v0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17]
+    eng = Engine(hp["layers"], lb, ub, pde="schrodinger", dtype=dtype)
+    eng.set_collocation(X_f)
+    eng.set_boundary(np.concatenate((0 * tb + lb[0], tb), 1), np.concatenate((0 * tb + ub[0], tb), 1))
+    eng.set_data(np.concatenate([x0, x0], 1), np.concatenate([u0, v0], 1))
+    eng.set_weights(g["w0"])
+    eng.adam_init(hp["tf_lr"], hp["tf_b1"], 0.999, hp["tf_eps"])
+    terms = eng.adam_run_terms(5)
+    losses = terms.sum(axis=1)
+    dl = float(np.max(np.abs(losses - g["adam_losses_compat"]) / g["adam_losses_compat"]))
+    dw = rel(eng.get_weights(), g["w_after_5"])
+    record(dtype=dtype, tag=tag, loss_dev=dl, w_after_5=dw)
+    assert abs(losses[0] - float(g["loss_compat"])) / float(g["loss_compat"]) < TOL[dtype]["loss"]
+    if dtype == "f64":
+        assert dl < 1e-8 and dw < 1e-8
+    else:                      # eps = 0.1 makes this Adam regime benign: float32 gradients move the weights by ~1e-6
+        assert dl < 2e-5 and dw < 2e-5
+    eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_tile16_ragged_last_chunk_stays_inside_its_rows(burgers_sets, record, dtype):
+    """regression (round-1 advisor): a short last chunk whose launch plan wants MORE workgroups than the full
+    32768-point chunk (n_pad = 42048 -> last chunk 9280 points = 580 groups > 2 x 256 rows) must not write
+    partial-gradient rows past the allocation; shape-generic MFMA sweeps vs the generic kernels at width 32 / 64"""
+    from oracle import init
+    from pinn_native import Engine
+    r = burgers_sets(100, 10000)
+    lb, ub = r[11], r[10]
+    rs = np.random.RandomState(11)
+    n_f = 42048 - 100 - 37            # n_all = 42011 -> n_pad = 42048
+    X_f = lb + (ub - lb) * rs.rand(n_f, 2)
+    for width in (32, 64):
+        layers = [2, width, width, width, 1]
+        w = init.glorot_flat(layers) + 0.02 * rs.standard_normal(sum(a * b + b for a, b in zip(layers[:-1], layers[1:])))
+        out = {}
+        for path in (4, 0):
+            eng = Engine(layers, lb, ub, pde="burgers", dtype=dtype)
+            eng.set_kernel_path(path)
+            eng.set_collocation(X_f)
+            eng.set_data(r[7], r[8])
+            eng.set_pde_params(NU)
+            eng.set_weights(w)
+            out[path] = eng.loss_grad()
+            again = eng.loss_grad()
+            assert again[0] == out[path][0] and np.array_equal(again[1], out[path][1])
+            eng.close()
+        dl = abs(out[4][0] - out[0][0]) / out[0][0]
+        dg = rel(out[4][1], out[0][1])
+        record(dtype=dtype, width=width, loss_dev=dl, grad_dev=dg)
+        assert dl < TOL[dtype]["loss"] * 3 and dg < TOL[dtype]["grad"] * 3, (width, dl, dg)
 
 
 @pytest.mark.parametrize("N_f", [1024, 50000])

@@ -65,15 +65,79 @@ def test_inf_cont_burgers_default_run_matches_reference_log(tmp_path, dtype):
     assert 0.24 <= end[1] <= 0.31, end                                      # reference: 2.6564e-01
 
 
-def test_ide_cont_burgers_runs_and_identifies(tmp_path):
-    hp = {"N_u": 2000, "layers": [2, 20, 20, 20, 20, 20, 20, 20, 20, 1], "tf_epochs": 100, "tf_lr": 0.001,
-          "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 300, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 50,
-          "dtype": "f64"}
+def test_ide_cont_burgers_run_matches_reference_log(tmp_path):
+    """1d-burgers/ide_cont_burgers.py, 100 Adam + 100 L-BFGS, both models (clean + the "noise" rerun), float64,
+    against the printed log and lambdas of the reference's own script (whitespace-repaired, make_golden.py):
+    every Adam line to 1.5e-4, the L-BFGS lines to 2 %, the identified lambdas to 2 %."""
+    g = json.load(open(golden("burgers_ide_run.json")))
+    hp = dict(g["hp"], dtype="f64")
     out = run_script(os.path.join("1d-burgers", "ide_cont_burgers.py"), hp, tmp_path)
+    mine = [l for l in out.splitlines() if l.startswith(("tf_epoch", "nt_epoch"))]
+    ref = [l for l in g["lines"] if l.startswith(("tf_epoch", "nt_epoch"))]
+    assert len(mine) == len(ref) == 2 * (10 + 9)
+    for a, b in zip(mine, ref):
+        ma, mb = LINE.match(a), LINE.match(b)
+        assert (ma.group(1), ma.group(2)) == (mb.group(1), mb.group(2))
+        la, lb_ = float(ma.group(3)), float(mb.group(3))
+        assert abs(la - lb_) <= (2e-2 if ma.group(1) == "nt_epoch" else 1.5e-4) * lb_, (a, b)
+    vals = dict(re.findall(r"^(l1|l2|l1_noise|l2_noise):\s+(\S+)$", out, flags=re.M))
+    for key, ref_key in (("l1", "lambda_1"), ("l2", "lambda_2"), ("l1_noise", "lambda_1_noise"), ("l2_noise", "lambda_2_noise")):
+        assert abs(float(vals[key]) - g[ref_key]) <= 2e-2 * abs(g[ref_key]), (key, vals[key], g[ref_key])
+    ends = [float(m.group(2)) for m in map(END.match, out.splitlines()) if m]
+    ref_ends = [float(m.group(2)) for m in map(END.match, g["lines"]) if m]
+    assert len(ends) == len(ref_ends) == 2
+    for a, b in zip(ends, ref_ends):
+        assert abs(a - b) <= 2e-2 * b, (ends, ref_ends)
+
+
+def test_inf_cont_schrodinger_log_and_loss_parts_match_reference(tmp_path):
+    """1dcomplex-schrodinger/inf_cont_schrodinger.py, 10 Adam epochs, float64, defaults (= the reference's
+    fit(x0 [N0,1], ...) call): the progress lines, the per-evaluation `mse_0 / mse_b / mse_f` lines of loss() (:128)
+    and the final error on |h| against the reference script's own stdout"""
+    g = json.load(open(golden("schrodinger_run.json")))
+    out = run_script(os.path.join("1dcomplex-schrodinger", "inf_cont_schrodinger.py"), dict(g["hp"], dtype="f64"), tmp_path)
     rows, end = parse(out)
-    assert rows and end is not None
-    assert rows[-1][2] < rows[0][2]                                         # the loss went down
-    assert "l1: " in out and "l2_noise: " in out                            # both fits reported
+    ref, ref_end = parse("\n".join(g["lines"]))
+    assert [(r[0], r[1]) for r in rows] == [(r[0], r[1]) for r in ref] and len(ref) == 10
+    for (_, ep, loss), (_, _, loss_ref) in zip(rows, ref):
+        assert abs(loss - loss_ref) <= 1.5e-4 * loss_ref, (ep, loss, loss_ref)
+    mse = [[float(t[1]), float(t[3]), float(t[5])] for t in (l.split() for l in out.splitlines() if l.startswith("mse_0"))]
+    assert len(mse) == len(g["mse_0_b_f"]) == 10
+    for a, b in zip(mse, g["mse_0_b_f"]):
+        for x, y in zip(a, b):
+            assert abs(x - y) <= 1e-8 * max(abs(y), 1e-12), (a, b)
+    assert end is not None and abs(end[1] - g["final_error"]) <= 1e-6, (end, g["final_error"])
+
+
+def test_plotting_and_result_directory(tmp_path):
+    """the scripts end like the reference's: utils/plotting.py:8-16 saveResultDir + burgersutil.py:133-206 write
+    results/<stamp>-<script>/{graph.pdf, graph.png, hp.json} (+ weights.npy: the flat vector)"""
+    import glob
+    import shutil
+    hp = {"N_u": 64, "N_f": 2048, "layers": [2, 20, 20, 20, 20, 20, 20, 20, 20, 1], "tf_epochs": 20, "tf_lr": 0.03,
+          "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 20, "nt_lr": 0.8, "nt_ncorr": 50, "log_frequency": 10, "dtype": "f32"}
+    res_dir = os.path.join(PKG, "1d-burgers", "results")
+    before = set(glob.glob(os.path.join(res_dir, "*")))
+    hp_file = tmp_path / "hp.json"
+    hp_file.write_text(json.dumps(hp))
+    env = dict(os.environ, MPLBACKEND="Agg")
+    env.pop("PINN_NO_PLOT", None)
+    res = subprocess.run([sys.executable, os.path.join(PKG, "1d-burgers", "inf_cont_burgers.py"), str(hp_file)],
+                         cwd=PKG, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    new = sorted(set(glob.glob(os.path.join(res_dir, "*"))) - before)
+    try:
+        assert len(new) == 1 and new[0].endswith("-inf_cont_burgers"), new
+        files = sorted(os.listdir(new[0]))
+        for need in ("graph.pdf", "graph.png", "hp.json"):
+            assert need in files and os.path.getsize(os.path.join(new[0], need)) > 0, files
+        assert json.load(open(os.path.join(new[0], "hp.json"))) == hp
+        import numpy as np
+        w = np.load(os.path.join(new[0], "weights.npy"))
+        assert w.shape == (3021,) and w.dtype == np.float64 and np.all(np.isfinite(w))
+    finally:
+        for d in new:
+            shutil.rmtree(d, ignore_errors=True)
 
 
 def test_inf_cont_schrodinger_runs(tmp_path):

@@ -9,6 +9,7 @@ import io
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -138,7 +139,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(pinn_native.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pinn_abi_version() == 2
+    assert lib.pinn_abi_version() == 3
     # plain C types only in the header
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
     assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
@@ -178,3 +179,32 @@ def test_engine_construction_fails_loudly_without_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(pinn_native.PinnNativeError):
         pinn_native.Engine([2, 20, 20, 1], [-1, 0], [1, 1])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_ide_cont_repair_is_whitespace_only_and_parses():
+    """tests/golden/repair_ide_cont.py holds an indent table, no reference text; applied to the reference's
+    ide_cont_burgers.py it changes leading blanks only (what `diff -w` checks) and the result compiles"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import repair_ide_cont
+    src = repair_ide_cont.check()
+    assert "class BurgersInformedNN" in src
+    with pytest.raises(SyntaxError):
+        compile(open(repair_ide_cont.REF_FILE, encoding="utf-8").read(), "ide_cont_burgers.py", "exec")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        dst = repair_ide_cont.write(os.path.join(d, "1d-burgers", "ide_cont_burgers.py"))
+        res = subprocess.run(["diff", "-w", repair_ide_cont.REF_FILE, dst], capture_output=True, text=True)
+        assert res.returncode == 0 and res.stdout == ""
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
+def test_oracle_ref_staging_copies_the_reference_files_verbatim():
+    import filecmp
+    from oracle import make_ref
+    assert make_ref.stage(verbose=False) and make_ref.staged()
+    for rel in make_ref.FILES:
+        assert filecmp.cmp(os.path.join("/root/reference", rel), os.path.join(make_ref.DST, rel), shallow=False)
+    # staged sources never enter the history
+    assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read()

@@ -147,16 +147,47 @@ def test_lbfgs_known_answer():
 
 @pytest.mark.parametrize("tag", ["_small", ""])
 def test_burgers_identification(tag):
-    import burgersutil
+    """oracle vs the reference's own ide_cont_burgers.py (whitespace-repaired, run over the shims): loss, gradient
+    incl. the lambda entries, residual, predict (u AND f at X_star, :169-172), Adam and L-BFGS trajectories"""
+    from oracle import mlp, optim
     g = np.load(golden("burgers_ide_eval%s.npz" % tag))
-    np.random.seed(1234)
-    r = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.0)
+    assert "reference ide_cont_burgers.py" in str(g["source"])
+    X_u, u = g["X_u"], g["u"]
+    lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
     layers = [2] + [20] * 8 + [1]
-    loss, grad, ex = pde.burgers_ide_loss_grad(g["w0"], layers, r[10], r[9], r[7], r[8])
+    loss, grad, ex = pde.burgers_ide_loss_grad(g["w0"], layers, lb, ub, X_u, u)
     assert abs(loss - float(g["loss"])) < 1e-14
     assert rel(grad, g["grad"]) < 1e-12
     assert abs(grad[-2] - g["grad"][-2]) < 1e-15 and abs(grad[-1] - g["grad"][-1]) < 1e-15
     assert np.max(np.abs(ex["f"][:64, 0] - g["f_first"])) < 1e-13
+    # the second model of the script draws from the continuing streams: its data is NOT the seed-1234 sample
+    import burgersutil
+    np.random.seed(1234)
+    r = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.0)
+    r2 = burgersutil.prep_data(BURGERS_MAT, int(g["N_u"]), noise=0.01)
+    assert not np.array_equal(r[7], X_u) and np.array_equal(r2[7], X_u) and np.array_equal(r2[8], u)
+    # Adam: 10 steps, lr 1e-3 (ide_cont_burgers.py:36-39)
+    adam = optim.Adam(1e-3, 0.9, 0.999, None)
+    w = g["w0"].copy()
+    losses = []
+    for it in range(10):
+        lo, gr, _ = pde.burgers_ide_loss_grad(w, layers, lb, ub, X_u, u)
+        losses.append(lo)
+        w = adam.step(w, gr)
+        if it == 0:
+            assert rel(w, g["adam_w_after_1"]) < 1e-13
+    assert np.max(np.abs(np.array(losses) - g["adam_losses"]) / g["adam_losses"]) < 1e-10
+    assert rel(w, g["adam_w_after_10"]) < 1e-10
+    # L-BFGS: 25 iterations through the reference driver semantics
+    args = []
+
+    def opfunc(x):
+        args.append(x.copy())
+        lo, gr, _ = pde.burgers_ide_loss_grad(x, layers, lb, ub, X_u, u)
+        return lo, gr
+    res = optim.lbfgs(opfunc, g["w0"].copy(), int(g["lbfgs_max_iter"]), 0.8, int(g["lbfgs_n_corr"]))
+    assert np.max(np.abs(np.array(res["f_hist"]) - g["lbfgs_f_hist"]) / np.abs(g["lbfgs_f_hist"])) < 1e-7
+    assert rel(res["x"], g["lbfgs_x_returned"]) < 1e-6 and rel(args[-1], g["lbfgs_w_model"]) < 1e-6
 
 
 def test_schrodinger_small(schrodinger_sets):
