@@ -106,7 +106,7 @@ def test_inf_cont_schrodinger_log_and_loss_parts_match_reference(tmp_path):
     for a, b in zip(mse, g["mse_0_b_f"]):
         for x, y in zip(a, b):
             assert abs(x - y) <= 1e-8 * max(abs(y), 1e-12), (a, b)
-    assert end is not None and abs(end[1] - g["final_error"]) <= 1e-6, (end, g["final_error"])
+    assert end is not None and abs(end[1] - g["final_error"]) <= 6e-5 * g["final_error"], (end, g["final_error"])   # 5 printed digits
 
 
 def test_plotting_and_result_directory(tmp_path):
