@@ -1,7 +1,8 @@
 // engine.hip -- context, device memory, launch sequencing and the C ABI (include/pinn_hip.h)
 // of the MI355X PINN engine.  Built for gfx950 only:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -shared -fPIC engine.hip \
-//         -o libpinn_hip.so -lrccl
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -c engine.hip
+//   hipcc ... -mllvm -amdgpu-mfma-vgpr-form=1 -fPIC -c fused20d_unit.hip          (see fused20d_api.h)
+//   hipcc --offload-arch=gfx950 -shared -fPIC engine.o fused20d_unit.o -o libpinn_hip.so -lrccl
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -16,6 +17,7 @@
 #include "../../include/pinn_hip.h"
 #include "kernels_fused20.h"
 #include "kernels_fused20m.h"
+#include "fused20d_api.h"
 #include "kernels_wide.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
@@ -88,6 +90,7 @@ struct pinn_ctx {
   double *theta = nullptr, *gl = nullptr, *adam_m = nullptr, *adam_v = nullptr;
   void* theta_r = nullptr;
   float* img = nullptr;              // LDS weight image of k_fused20m (f32 only)
+  int* row_index = nullptr;          // k_fused20d: entry of a wave's gradient block list -> flat parameter index
   int n_cu = 256, n_wg = 0;          // compute units; workgroups of the persistent kernel
   // device: scratch
   void *S = nullptr, *O = nullptr, *ZA = nullptr, *ZB = nullptr, *part = nullptr;
@@ -173,6 +176,12 @@ static bool fused_ok(const pinn_ctx* c) {
 static bool fused_regs_ok(const pinn_ctx* c) {
   return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER && !is_disc(c) &&
          c->nd.n_hidden == 8 && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
+}
+
+// the float64 register-stash kernel (kernels_fused20d.h): float64, width 20, 8 hidden layers, Burgers problems
+static bool fused_f64_ok(const pinn_ctx* c) {
+  return c->dtype == PINN_F64 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER && !is_disc(c) &&
+         c->nd.n_hidden == 8 && fused20d_lds_bytes(c->nd.n_hidden, c->nd.n_theta) <= 160 * 1024;
 }
 
 // the wide MFMA sweeps: float32, hidden width 100, two outputs (the Schrodinger net)
@@ -295,11 +304,12 @@ static int ensure_sets(pinn_ctx* c) {
   const size_t W = c->nd.width, H = c->nd.n_hidden;
   // the fused kernel keeps the whole set's stash (one launch); the generic path works in chunks
   const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
-  c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (path 2)
+  c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (paths 2 and 7)
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
-  const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : c->path == 2 ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
-  const size_t need_S = c->path == 2 ? 16 : H * W * stash_pts * 4 * rs;
-  const size_t need_Z = c->path == 2 ? 16 : W * (size_t)c->chunk * 4 * rs;
+  const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : (c->path == 2 || c->path == 7) ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
+  const bool no_stash = c->path == 2 || c->path == 7;
+  const size_t need_S = no_stash ? 16 : H * W * stash_pts * 4 * rs;
+  const size_t need_Z = no_stash ? 16 : W * (size_t)c->chunk * 4 * rs;
   const size_t need_part = rows * c->R * rs;
   if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
   if (need_Z > c->cap_Z) {
@@ -422,8 +432,16 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   const SetDesc sd = c->sd;
   const real lbx = (real)c->lb[0], lbt = (real)c->lb[1];
   const real sx = (real)(2.0 / (c->ub[0] - c->lb[0])), st = (real)(2.0 / (c->ub[1] - c->lb[1]));
-  if (ev4 && c->path != 2 && c->path != 1) HIPCHK(hipEventRecord(ev4[0], c->stream));
-  if (c->path == 2) {
+  if (ev4 && c->path != 2 && c->path != 1 && c->path != 7) HIPCHK(hipEventRecord(ev4[0], c->stream));
+  if (c->path == 7) {
+    int rc = hipErrorInvalidValue;
+    if constexpr (sizeof(real) == 8 && PDE != 2)
+      rc = fused20d_launch_any(PDE, c->nd, sd, (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts,
+                               (const double*)c->tgt, (double)lbx, (double)lbt, (double)sx, (double)st,
+                               (double)c->nu, (double*)c->part, c->R, c->n_wg, c->row_index, c->stream, c->stamps,
+                               ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
+    if (rc) return fail(PINN_EHIP, "fused20d launch failed: %s", hipGetErrorString((hipError_t)rc));
+  } else if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2)
       rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
@@ -501,7 +519,7 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   if (ev4) HIPCHK(hipEventRecord(ev4[2], c->stream));
   const int n_rows = t16_bwd_on(c) ? t16_wgs(c, c->chunk)
                    : c->path == 3 ? ((c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu)
-                   : c->path == 2 ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
+                   : (c->path == 2 || c->path == 7) ? c->n_wg : c->path == 1 ? fused20_rows(sd) : c->n_rows;
   return launch_reduce<real>(c, n_rows, af);
 }
 
@@ -877,7 +895,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   const size_t n = nd.n_theta;
   if (dev_alloc(&c->theta, n * 8) || dev_alloc(&c->gl, (size_t)c->R * 8) ||
       dev_alloc(&c->adam_m, n * 8) || dev_alloc(&c->adam_v, n * 8) ||
-      dev_alloc(&c->theta_r, n * real_size(c))) { delete c; return PINN_EHIP; }
+      dev_alloc(&c->theta_r, n * real_size(c) + 1024)) { delete c; return PINN_EHIP; }   // + one LDS-DMA piece of slack
   HIPCHK(hipMemsetAsync(c->theta, 0, n * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->theta_r, 0, n * real_size(c), c->stream));
   HIPCHK(hipMemsetAsync(c->gl, 0, (size_t)c->R * 8, c->stream));
@@ -894,6 +912,12 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
     HIPCHK(hipStreamSynchronize(c->stream));
   }
   if (fused_regs_ok(c)) nd.img_kind = 1;
+  if (fused_f64_ok(c)) {
+    std::vector<int> ri((size_t)fused20d_blocks(nd.n_hidden) * 16);
+    fused20d_row_index(nd, nd.n_hidden, ri.data());
+    if (dev_alloc(&c->row_index, ri.size() * sizeof(int))) { delete c; return PINN_EHIP; }
+    HIPCHK(hipMemcpy(c->row_index, ri.data(), ri.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   if (wide_ok(c)) {
     const size_t nimg = wide_image_floats<100>(nd.n_hidden);
     if (dev_alloc(&c->img, nimg * 4)) { delete c; return PINN_EHIP; }
@@ -901,9 +925,9 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
     HIPCHK(hipStreamSynchronize(c->stream));
     nd.img_kind = 2;
   }
-  // default kernel family: 2 width-20 f32 (MFMA GEMVs, register stash), 1 width-20 HBM-stash,
-  // 3 wide MFMA sweeps (width 100, 2 outputs), 0 generic
-  c->path = fused_regs_ok(c) ? 2 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : tile16_ok(c) ? 4 : 0;
+  // default kernel family: 2 width-20 f32 (MFMA GEMVs, register stash), 7 its float64 counterpart (4x4x4 MFMA GEMVs,
+  // no exchange), 1 width-20 HBM-stash, 3 wide MFMA sweeps (width 100, 2 outputs), 4 shape-generic MFMA sweeps, 0 generic
+  c->path = fused_regs_ok(c) ? 2 : fused_f64_ok(c) ? 7 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : tile16_ok(c) ? 4 : 0;
   *out = c;
   return 0;
 }
@@ -918,7 +942,7 @@ int pinn_destroy(pinn_ctx* c) {
                   c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
-                  c->lb_cy, c->lb_ex, c->img, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
+                  c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -1524,7 +1548,7 @@ int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n) {
   *n = c->ev_used;
   const double k = c->ev_used ? 1.0 / c->ev_used : 0.0;
   avg_ms[0] = a * k; avg_ms[1] = b * k; avg_ms[2] = t * k; avg_ms[3] = c->ev_overhead_ms;
-  avg_ms[4] = (c->path == 2 || c->path == 1) ? 1.0 : 0.0;
+  avg_ms[4] = (c->path == 2 || c->path == 1 || c->path == 7) ? 1.0 : 0.0;
   c->ev_used = 0;
   return 0;
 }
@@ -1537,9 +1561,12 @@ int pinn_sync(pinn_ctx* c) {
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
-  REQUIRE(c && path >= 0 && path <= 6, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
-          "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half)");
-  if (path >= 4) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
+  REQUIRE(c && path >= 0 && path <= 7, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
+          "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half), "
+          "7 (fused width-20 float64, register stash)");
+  if (path >= 4 && path <= 6) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
+  if (path == 7)
+    REQUIRE(fused_f64_ok(c), "the float64 register-stash path needs float64, hidden width 20, 8 hidden layers and a Burgers problem");
   if (path == 3) REQUIRE(wide_ok(c), "the wide path needs float32, hidden width 100 and two outputs");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");
@@ -1557,7 +1584,7 @@ int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves
   HIPCHK(hipSetDevice(c->device));
   int rc = ensure_sets(c);
   if (rc) return rc;
-  const size_t n = (size_t)(c->path == 2 ? c->n_wg : c->sd.n_pad / 64) * 4 * 32;
+  const size_t n = (size_t)((c->path == 2 || c->path == 7) ? c->n_wg : c->sd.n_pad / 64) * 4 * 32;
   REQUIRE((size_t)cap >= n, "stamp buffer too small: need %zu", n);
   if (dev_alloc(&c->stamps, n * 8)) return PINN_EHIP;
   HIPCHK(hipMemsetAsync(c->stamps, 0, n * 8, c->stream));

@@ -1,0 +1,431 @@
+// kernels_fused20d.h -- float64 loss+gradient kernel for width-20 tanh MLPs (k_fused20d): the reference's own
+// arithmetic (utils/neuralnetwork.py:24-26 is float64) with every contraction on v_mfma_f64_4x4x4_4b_f64 and no
+// inter-wave exchange at all.
+//
+// Why this shape.  Measured on gfx950 (profiles/r02_ubench_mfma_f64_4x4x4.txt): the instruction retires 4 blocks x
+// (4x4x4) = 256 MACs in 16.3 cycles = the FP64 rate of the SIMD (a v_fma_f64 costs 4-5 cycles for 64 MACs; the two
+// share the pipe, their times add), dependent-accumulator latency 20 cycles, and its lane maps are
+//     A[i][k] : lane 16k + 4b + i      B[k][j] : lane 16k + 4b + j      D[i][j] : lane 16i + 4b + j     (b = block)
+// i.e. D and B have the SAME map with the output row i in the place of the contraction index k.  Put a point on the
+// low four lane bits (q = 4b + j: 16 points per wave) and a feature slot s on the two high bits, five registers per
+// Taylor channel for the five groups of four features (feature = 4n + s), and a layer is
+//     out_c[n] += W-pattern[m][n] (A)  x  in_c[m] (B)            25 instructions per channel, 20 = 5 x 4: no padding
+// whose result registers ARE the next layer's B operands: lane = (slot, point) in, lane = (slot, point) out, for the
+// forward GEMV and (with the transposed pattern) for the reverse GEMV.  No LDS exchange tile, no barrier, no
+// cross-lane traffic in either sweep; tanh and the Taylor / adjoint algebra are lane-local.  The weight patterns
+// are plain ds_read_b64 of the flat weight vector (copied into LDS once per workgroup): lane (s, i = lane & 3) reads
+// W[4m+s][4n+i] (forward) or W[4m+i][4n+s] (reverse) -- conflict-free, no packed image needed.
+//
+// The weight gradient dW_d[k][j] = sum over (point, channel) IN_c[k] ZBAR_c[j] contracts over POINTS, so both
+// operands need the point index where the instruction contracts (lane bits 4-5) and the feature slot on bits 0-1:
+// a rotation of the lane index by two bits, one ds_bpermute pair per value (40 values per layer).  The four blocks
+// then hold partial sums over the points with q & 3 = b; they are folded with two DPP row rotations and added into a
+// per-wave accumulator in LDS (the accumulators of a wave: 221 blocks x 16 values = 28 KB, persistent over the
+// workgroup's tiles; summed over the four waves in fixed order at the end -> one gradient row per workgroup, no
+// atomics, bit-reproducible).  First and last dense layer run through the same block machinery (in-group
+// (h_x, h_t, 1) / single output column), so there is no per-lane gradient bookkeeping at all.
+//
+// Stash: (a, z_x, z_t, z_xx) of the 5 own features x 6 middle layers = 240 registers parked in AGPRs; layer 0 keeps
+// only a (its other channels are weight constants), the last hidden layer stays live in VGPRs.  One wave per SIMD,
+// four waves = 64 points per workgroup, persistent over tiles (grid = min(tiles, CUs)).
+//
+// Work per 64-point tile and hidden layer: 100 (forward) + 100 (reverse GEMV) + 105 (dW) instructions per wave =
+// 5.0k cycles of matrix pipe; algorithmic FLOP and bytes as k_fused20m (68 640 FLOP and 16 B per collocation point).
+//
+// Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of 1d-burgers/inf_cont_burgers.py:65-90 under the outer
+// tape of utils/neuralnetwork.py:55-59; identification (PDE == 1): 1d-burgers/ide_cont_burgers.py:56-91.
+#pragma once
+#include <hip/hip_ext.h>
+#include "kernels_fused20.h"
+#include "fused20d_api.h"
+
+namespace pinn {
+
+// a double parked in the accumulation half of the register file (two 32-bit AGPRs)
+struct agd { int lo, hi; };
+__device__ __forceinline__ agd agd_put(const double x) {
+  agd a;
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(lo));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.hi) : "v"(hi));
+  return a;
+}
+// The same for a value that comes straight out of a matrix instruction.  hipcc's hazard recogniser does not look
+// inside inline asm, so nothing would keep the v_accvgpr_write the required wait states behind the MFMA that
+// produces x (observed: stale low words, 1e-8 relative errors).  `after` must be the result of a compiler-visible
+// VALU instruction that reads x: the extra operand orders the asm behind that instruction, whose own hazard wait
+// the compiler did insert.
+__device__ __forceinline__ agd agd_put_after(const double x, const double after) {
+  agd a;
+  const int lo = __double2loint(x), hi = __double2hiint(x), dep = __double2hiint(after);
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(lo), "v"(dep));
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.hi) : "v"(hi), "v"(dep));
+  return a;
+}
+__device__ __forceinline__ double agd_get(const agd a) {
+  int lo, hi;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo));
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double mfma444(const double a, const double b, const double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// value of lane (src4 >> 2) -- any permutation of the wave, 2 x ds_bpermute_b32
+__device__ __forceinline__ double lane_fetch(const double x, const int src4) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
+
+// layer-output channels (h, p, q, r) of a stash entry (a, zp, zq, zr)           (A.1)
+__device__ __forceinline__ void channels_d(const double a, const double zp, const double zq, const double zr,
+                                           double& h, double& p, double& q, double& r) {
+  const double d1 = __builtin_fma(-a, a, 1.0);
+  const double t = (-2.0 * a) * zp;
+  h = a; p = d1 * zp; q = d1 * zq; r = d1 * __builtin_fma(t, zp, zr);
+}
+
+// adjoint of the pre-activation channels                                          (A.3)
+__device__ __forceinline__ void preact_adjoint_d(const double a, const double zp, const double zq, const double zr,
+                                                 const double oh, const double op, const double oq, const double orr,
+                                                 double& bh, double& bp, double& bq, double& br) {
+  const double a2 = a * a, d1 = 1.0 - a2;
+  const double d2 = (-2.0 * a) * d1;
+  const double d3 = (-2.0 * d1) * __builtin_fma(-3.0, a2, 1.0);
+  const double zpw = zp * orr;
+  const double dot = __builtin_fma(zr, orr, __builtin_fma(zq, oq, zp * op));
+  bh = __builtin_fma(d3 * zp, zpw, __builtin_fma(d2, dot, d1 * oh));
+  bp = __builtin_fma(d2 + d2, zpw, d1 * op);
+  bq = d1 * oq;
+  br = d1 * orr;
+}
+
+template <int PDE, int H>
+__global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const double* __restrict__ th,
+                                                  const double* __restrict__ xs, const double* __restrict__ ts,
+                                                  const double* __restrict__ tgt, double lbx, double lbt, double sx,
+                                                  double st, double nu, double* __restrict__ part, int R,
+                                                  int n_tiles, const int* __restrict__ row_index,
+                                                  long long* __restrict__ stamps) {
+  constexpr int NBLK = fused20d_blocks(H);
+  constexpr int BLK_H = 5 + (H - 1) * 30;            // first block of dense H
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  double* const wl = reinterpret_cast<double*>(lds_raw);
+  const int nwp = (nd.n_theta + 127) / 128 * 128;
+  double* const gacc_all = wl + nwp;
+
+  STAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = lane & 15;                 // point of this wave's 16
+  const int s = lane >> 4;                 // feature slot: feature = 4 * group + s
+  const int i4 = lane & 3;                 // row / column slot of the A patterns and of the gradient blocks
+  const int pf = s * FW + i4;              // forward pattern:  W[4m + s][4n + i4]
+  const int pr = i4 * FW + s;              // reverse pattern:  W[4m + i4][4n + s]
+  const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   // lane-index rotation by two bits (bpermute address)
+  double* const gacc = gacc_all + wave * (NBLK * 16);
+  const int ge = s * 4 + i4;               // this lane's entry of a gradient block (valid where (lane >> 2) & 3 == 0)
+
+  // ---- flat weight vector -> LDS by asynchronous LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no
+  // registers; the engine pads the vector's allocation to whole pieces), gradient accumulators <- 0 meanwhile
+  for (int c = wave; c < nwp / 128; c += 4)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(th + c * 128 + lane * 2),
+                                     (__attribute__((address_space(3))) void*)(wl + c * 128), 16, 0, 0);
+  for (int i = tid; i < 4 * NBLK * 16; i += 256) gacc_all[i] = 0.0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  double c1 = 1.0, c2 = nu;
+  if (PDE == 1) { c1 = wl[nd.n_net]; c2 = exp(wl[nd.n_net + 1]); }
+  const double inv_nf = sd.inv_nf, inv_nu = sd.inv_nu;
+  double l_res = 0.0, l_dat = 0.0, dl0 = 0.0, dl1 = 0.0;       // per-lane partial sums (slot-0 lanes only)
+  const double onesA = i4 == 0 ? 1.0 : 0.0;                     // rotated "ones" in-group: row 0 = 1 (bias gradients)
+
+  // Gradient blocks.  D = this lane's partial sum over the four points of its block b; the four blocks of an entry
+  // are folded with two DPP row rotations -- commutative, so the four lanes of an entry end with bit-identical
+  // totals and may all store (same value, same address: no exec masking, no branch).  The old accumulator values
+  // are fetched BEFORE the matrix instructions that produce D (grad_fetch), so no LDS round trip is exposed.
+  auto grad_fetch = [&](const int blk) { return gacc[blk * 16 + ge]; };
+  auto grad_store = [&](double D, const double old, const int blk) {
+    D += dpp_mov<DPP_ROW_ROR8>(D);
+    D += dpp_mov<DPP_ROW_ROR4>(D);
+    gacc[blk * 16 + ge] = old + D;
+  };
+
+  int tile = blockIdx.x;
+  double x = 0.0, t = 0.0;
+  if (tile < n_tiles) { x = xs[tile * 64 + wave * 16 + q]; t = ts[tile * 64 + wave * 16 + q]; }
+  STAMP(1);
+
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int pt = tile * 64 + wave * 16 + q;
+    const double hx = __builtin_fma(sx, x - lbx, -1.0), ht = __builtin_fma(st, t - lbt, -1.0);
+    {
+      const int nt = tile + gridDim.x;
+      if (nt < n_tiles) { x = xs[nt * 64 + wave * 16 + q]; t = ts[nt * 64 + wave * 16 + q]; }
+    }
+
+    // ------------------------------------------------------------------ forward
+    double in[4][5];                         // [channel h,p,q,r][group]: outputs of the layer below, own (slot, point)
+    double a0[5];                            // layer 0: tanh outputs (its z_x, z_t are weight constants, z_xx = 0)
+    agd stash[H][5][4];                      // AGPR-resident, layers 1..H-2
+    double top[5][4];                        // last hidden layer's stash entry, live across the seeds
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {            // dense 0: p0 = (sx, 0), q0 = (0, st), r0 = 0
+      const int f = 4 * n + s;
+      const double w0x = wl[nd.off_w[0] + f], w0t = wl[nd.off_w[0] + FW + f], b0 = wl[nd.off_b[0] + f];
+      const double a = tanh_bf(__builtin_fma(hx, w0x, __builtin_fma(ht, w0t, b0)));
+      a0[n] = a;
+      channels_d(a, sx * w0x, st * w0t, 0.0, in[0][n], in[1][n], in[2][n], in[3][n]);
+    }
+#pragma unroll
+    for (int d = 1; d < H; ++d) {
+      const double* __restrict__ wd = wl + nd.off_w[d] + pf;
+      double acc[4][5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        acc[0][n] = wl[nd.off_b[d] + 4 * n + s];
+        acc[1][n] = acc[2][n] = acc[3][n] = 0.0;
+      }
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) {
+          const double A = wd[80 * m + 4 * n];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        const double a = tanh_bf(acc[0][n]);
+        channels_d(a, acc[1][n], acc[2][n], acc[3][n], in[0][n], in[1][n], in[2][n], in[3][n]);
+        if (d < H - 1) {       // a is a VALU result; z_x, z_t, z_xx are raw matrix results (see agd_put_after)
+          stash[d][n][0] = agd_put(a); stash[d][n][1] = agd_put_after(acc[1][n], in[1][n]);
+          stash[d][n][2] = agd_put_after(acc[2][n], in[2][n]); stash[d][n][3] = agd_put_after(acc[3][n], in[3][n]);
+        } else {
+          top[n][0] = a; top[n][1] = acc[1][n]; top[n][2] = acc[2][n]; top[n][3] = acc[3][n];
+        }
+      }
+      STAMP(1 + d);
+    }
+    // linear output layer: the pattern does not depend on the row, so all four slot lanes of a point get
+    // o = (u, u_x, u_t, u_xx)
+    double o[4] = {wl[nd.off_b[H]], 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < 5; ++m) {
+      const double A = wl[nd.off_w[H] + 4 * m + s];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = mfma444(A, in[c][m], o[c]);
+    }
+
+    // ------------------------------------------------------------------ seeds + loss parts
+    double sb[4] = {0.0, 0.0, 0.0, 0.0};
+    {
+      const int cls = point_class(sd, pt);
+      const bool res = (PDE == 0) ? (cls == CLS_COL) : (cls == CLS_DATA);
+      if (res) {
+        const double wgt = (PDE == 0) ? inv_nf : inv_nu;
+        const double f = o[2] + c1 * o[0] * o[1] - c2 * o[3];
+        const double fbar = 2.0 * f * wgt;
+        if (s == 0) {
+          l_res += f * f * wgt;
+          if (PDE == 1) { dl0 += fbar * o[0] * o[1]; dl1 -= fbar * c2 * o[3]; }
+        }
+        sb[0] = fbar * c1 * o[1]; sb[1] = fbar * c1 * o[0]; sb[2] = fbar; sb[3] = -c2 * fbar;
+      }
+      if (cls == CLS_DATA) {
+        const double dd = o[0] - tgt[pt];
+        if (s == 0) l_dat += dd * dd * inv_nu;
+        sb[0] += 2.0 * dd * inv_nu;
+      }
+    }
+
+    // ------------------------------------------------------------------ reverse sweep
+    double ob[4][5];                         // adjoint of the outputs of the layer below, own (slot, point)
+    {  // dense H (linear, one output): z_bar = sb.  dW_H[k] = sum IN_c[k] sb_c, db_H = sum sb_h
+      double sbT[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) sbT[c] = lane_fetch(s == 0 ? sb[c] : 0.0, rot4);     // column 0 only
+      {
+        double D[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, old[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) old[m] = grad_fetch(BLK_H + m);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) D[m] = mfma444(lane_fetch(in[c][m], rot4), sbT[c], D[m]);
+        }
+        D[5] = mfma444(onesA, sbT[0], 0.0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) grad_store(D[m], old[m], BLK_H + m);
+      }
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        const double w = wl[nd.off_w[H] + 4 * n + s];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ob[c][n] = sb[c] * w;
+      }
+    }
+    STAMP(H + 1);
+#pragma unroll
+    for (int d = H - 1; d >= 1; --d) {
+      // pre-activation adjoints of layer d, and their point-major (rotated) copies for the weight gradient
+      double zb[4][5], zbT[4][5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        double a, zp, zq, zr;
+        if (d == H - 1) { a = top[n][0]; zp = top[n][1]; zq = top[n][2]; zr = top[n][3]; }
+        else { a = agd_get(stash[d][n][0]); zp = agd_get(stash[d][n][1]); zq = agd_get(stash[d][n][2]); zr = agd_get(stash[d][n][3]); }
+        preact_adjoint_d(a, zp, zq, zr, ob[0][n], ob[1][n], ob[2][n], ob[3][n], zb[0][n], zb[1][n], zb[2][n], zb[3][n]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zbT[c][n] = lane_fetch(zb[c][n], rot4);
+      }
+      // adjoint of the layer-(d-1) outputs: in_bar[4m + i] = sum_j z_bar_j W_d[4m + i][j]
+      const double* __restrict__ wd = wl + nd.off_w[d] + pr;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        ob[0][m] = ob[1][m] = ob[2][m] = ob[3][m] = 0.0;
+      }
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          const double A = wd[80 * m + 4 * n];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
+        }
+      }
+      // layer-(d-1) output channels, rotated: the A operands of the weight gradient
+      double inT[4][5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {
+        double a, zp, zq, zr;
+        if (d - 1 == 0) {
+          const int f = 4 * m + s;
+          a = a0[m]; zp = sx * wl[nd.off_w[0] + f]; zq = st * wl[nd.off_w[0] + FW + f]; zr = 0.0;
+        } else {
+          a = agd_get(stash[d - 1][m][0]); zp = agd_get(stash[d - 1][m][1]);
+          zq = agd_get(stash[d - 1][m][2]); zr = agd_get(stash[d - 1][m][3]);
+        }
+        double h, p, qq, r;
+        channels_d(a, zp, zq, zr, h, p, qq, r);
+        inT[0][m] = lane_fetch(h, rot4); inT[1][m] = lane_fetch(p, rot4);
+        inT[2][m] = lane_fetch(qq, rot4); inT[3][m] = lane_fetch(r, rot4);
+      }
+      // dW_d[4m + i][4n + j] and db_d[4n + j] (row 0 of the ones in-group)
+      const int base = 5 + (d - 1) * 30;
+#pragma unroll
+      for (int m = 0; m < 5; ++m) {          // five independent accumulator chains per in-group
+        double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) old[n] = grad_fetch(base + m * 5 + n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+          for (int n = 0; n < 5; ++n) D[n] = mfma444(inT[c][m], zbT[c][n], D[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + m * 5 + n);
+      }
+      {
+        double D[5], old[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) old[n] = grad_fetch(base + 25 + n);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) D[n] = mfma444(onesA, zbT[0][n], 0.0);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + 25 + n);
+      }
+      STAMP(2 * H + 1 - d);
+    }
+    {  // dense 0: inputs (hx, ht, 1) in channel h, (sx, 0, 0) in channel p, (0, st, 0) in channel q
+      const double hxT = lane_fetch(hx, rot4), htT = lane_fetch(ht, rot4);
+      const double Ah = i4 == 0 ? hxT : i4 == 1 ? htT : i4 == 2 ? 1.0 : 0.0;
+      const double Ap = i4 == 0 ? sx : 0.0, Aq = i4 == 1 ? st : 0.0;
+      double bT[3][5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) {
+        const int f = 4 * n + s;
+        double bh, bp, bq, br;
+        preact_adjoint_d(a0[n], sx * wl[nd.off_w[0] + f], st * wl[nd.off_w[0] + FW + f], 0.0, ob[0][n], ob[1][n],
+                         ob[2][n], ob[3][n], bh, bp, bq, br);
+        bT[0][n] = lane_fetch(bh, rot4); bT[1][n] = lane_fetch(bp, rot4); bT[2][n] = lane_fetch(bq, rot4);
+      }
+      double D[5], old[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) old[n] = grad_fetch(n);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) D[n] = mfma444(Ah, bT[0][n], 0.0);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) D[n] = mfma444(Ap, bT[1][n], D[n]);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) D[n] = mfma444(Aq, bT[2][n], D[n]);
+#pragma unroll
+      for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], n);
+    }
+  }
+  STAMP(2 * H + 1);
+
+  // -------------------------------------------------------------------- one gradient row per workgroup
+  {
+    const double t0 = wave_sum(l_res), t1 = wave_sum(l_dat), t2 = wave_sum(dl0), t3 = wave_sum(dl1);
+    __syncthreads();                                   // every wave's accumulators are final
+    double* const scal = wl;                           // the weight copy is dead: 4 x 4 loss / lambda partials
+    if (lane == 0) { scal[wave * 4 + 0] = t0; scal[wave * 4 + 1] = t1; scal[wave * 4 + 2] = t2; scal[wave * 4 + 3] = t3; }
+    __syncthreads();
+    double* __restrict__ row = part + (size_t)blockIdx.x * R;
+    // row_index[e]: flat parameter index of entry e of the block list (-1: padding), built once on the host
+    constexpr int NE = NBLK * 16, NIT = (NE + 255) / 256;
+    int idx[NIT];
+    double v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 256 * it;
+      idx[it] = e < NE ? row_index[e] : -1;
+      const int ee = e < NE ? e : 0;
+      v[it] = ((gacc_all[ee] + gacc_all[NE + ee]) + gacc_all[2 * NE + ee]) + gacc_all[3 * NE + ee];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (idx[it] >= 0) row[idx[it]] = v[it];
+    if (tid < 4) {
+      const double v = ((scal[tid] + scal[4 + tid]) + scal[8 + tid]) + scal[12 + tid];
+      if (tid == 0) { row[nd.n_theta + 0] = v; row[nd.n_theta + 2] = 0.0; }
+      if (tid == 1) row[nd.n_theta + 1] = v;
+      if (PDE == 1 && tid == 2) row[nd.n_net] = v;
+      if (PDE == 1 && tid == 3) row[nd.n_net + 1] = v;
+    }
+  }
+  STAMP(2 * H + 2);
+}
+
+// returns a hipError_t (0 = ok)
+template <int PDE, int H>
+inline int fused20d_launch(const NetDesc& nd, const SetDesc& sd, const double* th, const double* xs, const double* ts,
+                           const double* tgt, double lbx, double lbt, double sx, double st, double nu, double* part,
+                           int R, int n_wg, const int* row_index, hipStream_t stream, long long* stamps = nullptr,
+                           hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+  const size_t lds = fused20d_lds_bytes(H, nd.n_theta);
+  static unsigned long long attr_set = 0;
+  if (first_call_on_device(attr_set)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused20d<PDE, H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (ev_start && ev_stop)
+    hipExtLaunchKernelGGL((k_fused20d<PDE, H>), dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd, th,
+                          xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, row_index, stamps);
+  else
+    hipLaunchKernelGGL((k_fused20d<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, xs, ts, tgt, lbx, lbt,
+                       sx, st, nu, part, R, sd.n_pad / 64, row_index, stamps);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pinn

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_wide.h",
+SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h",
            "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
@@ -49,15 +49,31 @@ def build(force=False, verbose=False, stamps=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC",
-           os.path.join(_CSRC, "engine.hip"), "-o", out + ".tmp", "-lrccl"]
+    # two translation units (compiled concurrently), one shared object: k_fused20d wants its matrix results in
+    # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
     if stamps:
-        cmd.insert(1, "-DPINN_STAMPS")
+        common.append("-DPINN_STAMPS")
+    tag = "_stamps" if stamps else ""
+    units = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])]
+    objs, procs = [], []
+    for src, extra in units:
+        obj = os.path.join(_HERE, os.path.splitext(src)[0] + tag + ".o")
+        cmd = common + extra + ["-c", os.path.join(_CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        log = pr.communicate()[0]
+        if pr.returncode != 0:
+            raise PinnNativeError("hipcc failed (%s):\n%s" % (" ".join(cmd), log))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp", "-lrccl"]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise PinnNativeError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise PinnNativeError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(out + ".tmp", out)
     return out
 

@@ -33,16 +33,17 @@ def main():
     st = eng.debug_stamps().astype(np.float64)          # [n_waves, 32]
     H = len(bench.LAYERS) - 2
     path = eng.kernel_path()
-    n_st = 2 * H + 3 if path == 2 else 2 * H + 2
+    n_st = 2 * H + 3 if path in (2, 7) else 2 * H + 2
     if len(sys.argv) > 3:
         eng.set_kernel_path(int(sys.argv[3]))
         path = eng.kernel_path()
+        n_st = 2 * H + 3 if path in (2, 7) else 2 * H + 2
         st = eng.debug_stamps().astype(np.float64)
     st = st[:, :n_st].reshape(-1, 4, n_st)              # [wg, wave, stamp]
     t0 = st[:, :, 0].min()
     names = (["stage weights + dense0"] + ["fwd dense %d" % d for d in range(1, H)] +
              ["output + seeds + bwd dense %d" % H] + ["bwd dense %d" % d for d in range(H - 1, 0, -1)] +
-             (["bwd dense 0", "epilogue: wave sums + gradient row"] if path == 2 else ["bwd dense 0 + stores"]))
+             (["bwd dense 0", "epilogue: wave sums + gradient row"] if path in (2, 7) else ["bwd dense 0 + stores"]))
     dur = np.diff(st, axis=2)                           # [wg, wave, phase]
     wg_total = st[:, :, -1].max(axis=1) - st[:, :, 0].min(axis=1)
     print("# %s N_f=%d workgroups=%d  (ticks = shader cycles via s_memtime)" % (dtype, n_f, st.shape[0]))

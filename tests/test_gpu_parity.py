@@ -46,7 +46,7 @@ def make_burgers(sets, N_u, N_f, dtype, path=None):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("path", [0, 1, 2, 7])
 @pytest.mark.parametrize("tag,N_u,N_f", [("_small", 64, 2048), ("", 100, 10000)])
 def test_burgers_eval_vs_golden_and_oracle(burgers_sets, dtype, path, tag, N_u, N_f):
     from oracle import pde
@@ -215,6 +215,29 @@ def _ide_engine(g, dtype):
     assert eng.n_params == 3023
     eng.set_data(g["X_u"], g["u"])
     return eng, layers, lb, ub
+
+
+@pytest.mark.parametrize("N_f", [40000, 100001])
+def test_burgers_persistent_tiles_f64(burgers_sets, N_f):
+    """the float64 register-stash kernel (path 7: 16 points per wave, gradient blocks accumulated in LDS over the
+    workgroup's tiles) with more tiles than compute units: against the oracle, the generic kernels, and itself"""
+    from oracle import pde
+    g = np.load(golden("burgers_eval.npz"))
+    eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, 100, N_f, "f64", 7)
+    rs = np.random.RandomState(11)
+    w1 = g["w0"] + 0.05 * rs.standard_normal(g["w0"].size)
+    eng.set_weights(w1)
+    loss, grad, _ = eng.loss_grad()
+    lo, go, _ = pde.burgers_loss_grad(w1, layers, lb, ub, X_f, X_u, u, NU)
+    assert abs(loss - lo) / lo < TOL["f64"]["loss"]
+    assert rel(grad, go) < TOL["f64"]["grad"]
+    loss_b, grad_b, _ = eng.loss_grad()                  # bit-reproducible run to run
+    assert loss_b == loss and np.array_equal(grad_b, grad)
+    eng.set_kernel_path(0)
+    loss0, grad0, _ = eng.loss_grad()
+    assert abs(loss - loss0) / loss0 < TOL["f64"]["loss"]
+    assert rel(grad, grad0) < TOL["f64"]["grad"]
+    eng.close()
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -442,7 +465,7 @@ def test_burgers_ragged_and_tiny_sets(burgers_sets, dtype, N_u, N_f):
         up = mlp.forward_value(mlp.unpack(w, layers), X_u, lb, ub)
         lo, go = float(np.mean((up - u) ** 2)), None
     tol = TOL[dtype]
-    for path in (0, 1, 2):
+    for path in (0, 1, 2, 7):
         eng = Engine(layers, lb, ub, pde="burgers", dtype=dtype)
         try:
             eng.set_kernel_path(path)
