@@ -82,6 +82,21 @@ __device__ __forceinline__ double lane_fetch(const double x, const int src4) {
 
 constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 
+// tanh(x) = sign(x) (1 - t) / (1 + t), t = e^{-2|x|}: the denominator lies in (1, 2], so the quotient needs none of
+// the scaling / fix-up of an IEEE division: v_rcp_f64 seed + two Newton steps (relative error < 1e-30 before the
+// final rounding), 5 instructions instead of 11.
+__device__ __forceinline__ double tanh_d(const double x) {
+  const double t = exp(-2.0 * fabs(x));
+  const double y = 1.0 + t;
+  double r = __builtin_amdgcn_rcp(y);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-y, r, 1.0), r, r);
+  const double num = 1.0 - t;
+  double qv = num * r;
+  qv = __builtin_fma(__builtin_fma(-y, qv, num), r, qv);      // one correction of the quotient itself
+  return copysign(qv, x);
+}
+
 // layer-output channels (h, p, q, r) of a stash entry (a, zp, zq, zr)           (A.1)
 __device__ __forceinline__ void channels_d(const double a, const double zp, const double zq, const double zr,
                                            double& h, double& p, double& q, double& r) {
@@ -137,7 +152,11 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
   for (int c = wave; c < nwp / 128; c += 4)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(th + c * 128 + lane * 2),
                                      (__attribute__((address_space(3))) void*)(wl + c * 128), 16, 0, 0);
-  for (int i = tid; i < 4 * NBLK * 16; i += 256) gacc_all[i] = 0.0;
+  {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* const z = reinterpret_cast<d2*>(gacc_all);
+    for (int i = tid; i < 2 * NBLK * 16; i += 256) z[i] = d2{0.0, 0.0};
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -157,6 +176,8 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
     D += dpp_mov<DPP_ROW_ROR4>(D);
     gacc[blk * 16 + ge] = old + D;
   };
+  // (Tried: ds_add_f64 with the four lanes of an entry hitting one address, no fold, no read-modify-write --
+  //  221 instructions instead of ~3000, bit-reproducible over 200 runs, and 14 % SLOWER: 49.8 vs 43.7 us per step.)
 
   int tile = blockIdx.x;
   double x = 0.0, t = 0.0;
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
     for (int n = 0; n < 5; ++n) {            // dense 0: p0 = (sx, 0), q0 = (0, st), r0 = 0
       const int f = 4 * n + s;
       const double w0x = wl[nd.off_w[0] + f], w0t = wl[nd.off_w[0] + FW + f], b0 = wl[nd.off_b[0] + f];
-      const double a = tanh_bf(__builtin_fma(hx, w0x, __builtin_fma(ht, w0t, b0)));
+      const double a = tanh_d(__builtin_fma(hx, w0x, __builtin_fma(ht, w0t, b0)));
       a0[n] = a;
       channels_d(a, sx * w0x, st * w0t, 0.0, in[0][n], in[1][n], in[2][n], in[3][n]);
     }
@@ -204,7 +225,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
       }
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
-        const double a = tanh_bf(acc[0][n]);
+        const double a = tanh_d(acc[0][n]);
         channels_d(a, acc[1][n], acc[2][n], acc[3][n], in[0][n], in[1][n], in[2][n], in[3][n]);
         if (d < H - 1) {       // a is a VALU result; z_x, z_t, z_xx are raw matrix results (see agd_put_after)
           stash[d][n][0] = agd_put(a); stash[d][n][1] = agd_put_after(acc[1][n], in[1][n]);
