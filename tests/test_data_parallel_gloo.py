@@ -201,3 +201,88 @@ def test_bench_blocks_are_max_over_ranks_and_identical_everywhere(tmp_path):
     assert all(t >= 3 * 0.010 for t in times)                    # 3 steps of the slow rank
     assert sum(times) >= 0.100 and sum(times[:-1]) < 0.100       # stops once >= 100 ms are timed
     assert int(outs[0][1]) == int(outs[1][1]) == 3 * len(times)  # exactly K steps per block on every rank
+
+
+# ---- bench.py end to end at world size 2 (gloo) with a scripted engine: control flow, legs, JSON contract -----------------
+class _StubEngine(object):
+    """what bench.py touches of pinn_native.Engine; 'training' = a deterministic walk of the weight vector"""
+    made = []
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f32", device=0):
+        self.dtype, self.n_params, self.w = dtype, 3021, np.zeros(3021)
+        self.n_f = self.n_u = 0
+        self.comm = None
+        _StubEngine.made.append(self)
+
+    def set_collocation(self, X, n_total=None): self.n_f, self.n_f_total = len(X), n_total
+    def set_data(self, X, u, n_total=None): self.n_u = len(X)
+    def set_pde_params(self, *p): pass
+    def set_kernel_path(self, p): pass
+    def kernel_path(self): return 2 if self.dtype == "f32" else 7
+    def set_weights(self, w): self.w = np.array(w, dtype=np.float64)
+    def get_weights(self): return self.w.copy()
+    def adam_init(self, *a): pass
+    def adam_run(self, n, want_losses=True): self.w = self.w + 1e-3 * n
+    def lbfgs_begin(self, n, *a): self.left = n
+    def lbfgs_run(self, n): self.w = self.w - 1e-4 * self.left; return np.zeros(0, np.int32), np.zeros(0), 1
+    def sync(self): pass
+    def timing_enable(self, n, every=1): pass
+    def timing_read(self): return {"fwd_ms": 0.03, "sweeps_ms": 0.03, "eval_ms": 0.04, "empty_bracket_ms": 0.005, "kernel_exact": True, "n": 32}
+    def predict(self, X): return np.zeros((len(X), 1))
+    def comm_init(self, uid, world, rank): self.comm = (bytes(uid), world, rank)
+    def comm_set_mode(self, m): pass
+    def close(self): pass
+
+    @staticmethod
+    def comm_unique_id(): return b"u" * 128
+
+
+def _bench_main_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("PINN_COMM", None)
+    import contextlib
+    import io
+    import pinn_native
+    import bench
+    pinn_native.Engine = _StubEngine
+    pinn_native.device_info = lambda d=0: {"name": "stub", "compute_units": 256, "hbm_bytes": 0}
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "6", "--warmup", "3"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    with open(os.path.join(out_dir, "rank%d.out" % rank), "w") as f:
+        f.write(buf.getvalue())
+    with open(os.path.join(out_dir, "rank%d.sets" % rank), "w") as f:
+        f.write(";".join("%s:%d:%s" % (e.dtype, e.n_f, e.comm[1:] if e.comm else None) for e in _StubEngine.made))
+
+
+def test_bench_main_world2_emits_one_contract_line(tmp_path):
+    """python -m torch.distributed.run ... bench.py --gpus 2, with the engine scripted: rank 0 prints exactly one JSON
+    line carrying the contract keys; the metric's N_f = 10000 and cfg 5's N_f = 10^6 are SPLIT over the ranks (strong
+    scaling), every leg's engine joined a 2-rank communicator, nothing is printed by rank 1"""
+    import json
+    port = 29400 + os.getpid() % 100
+    mp.spawn(_bench_main_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out0 = open(tmp_path / "rank0.out").read().strip().splitlines()
+    assert open(tmp_path / "rank1.out").read().strip() == ""
+    assert len(out0) == 1
+    j = json.loads(out0[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 3 and j["scaling"] == "strong"
+    assert j["vs_baseline"] is None and j["cpu_baseline"] is None and j["higher_is_better"] is True
+    assert j["config"]["n_f_total"] == 10000 and j["config"]["n_f_per_gpu"] == 5000 and j["config"]["parallelism"] == "dp2"
+    assert j["config"]["allreduce"] == "rccl" and j["config"]["replicas_identical"] is True
+    assert abs(j["value"] - 10000 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in j["roofline"]
+    assert j["cfg5_leg"]["n_f_total"] == 1000000 and j["cfg5_leg"]["n_f_per_gpu"] == 500000
+    assert j["float64_leg"]["dtype"] == "f64" and j["float64_leg"]["kernel_path"] == 7
+    for r in range(2):
+        sets = open(tmp_path / ("rank%d.sets" % r)).read().split(";")
+        assert sets == ["f32:5000:(2, %d)" % r, "f64:5000:(2, %d)" % r, "f32:500000:(2, %d)" % r], sets
