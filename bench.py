@@ -11,7 +11,7 @@ strong scaling, honest for a 40-microsecond step), Adam then L-BFGS in the refer
 default epochs, 1d-burgers/inf_cont_burgers.py:35-41), canonical glorot init, inputs resident in HBM.
 
 Timing: W untimed warm-up steps; then blocks of EXACTLY K steps, each bracketed by barrier + stream sync on both sides
-and reduced with MAX over ranks; blocks are repeated (same initial state each time, reset outside the bracket) until
+(barrier + sync before, sync + MAX-over-ranks reduction after) ; blocks are repeated (same initial state each time, reset outside the bracket) until
 >= 50 ms have been timed, and the MEDIAN block is reported -- a single 20-step block is 1 ms, below the noise of a
 fresh box.  `value` = N_f_total x K / median block.  The kernel duration behind `roofline` is measured live in a
 separate pass of the same steps with HIP events attached to the launches themselves (>= 32 samples).
@@ -123,11 +123,14 @@ def time_blocks(eng, wd, w0, k_adam, k_lbfgs, min_ms=MIN_TIMED_MS, max_blocks=MA
     times, done = [], 1
     while (sum(times) * 1e3 < min_ms and len(times) < max_blocks) or not times:
         reset(eng, w0)
-        wd.barrier(eng)
+        wd.barrier(eng)                                    # everybody starts together ...
         t0 = time.perf_counter()
         done = run_steps(eng, k_adam, k_lbfgs)
-        wd.barrier(eng)
-        times.append(wd.max(time.perf_counter() - t0))
+        eng.sync()                                         # ... this rank's K steps are complete on its GPU ...
+        dt = time.perf_counter() - t0
+        times.append(wd.max(dt))                           # ... and the block lasts as long as the slowest rank
+        # (the MAX all-reduce is also the closing barrier; it sits outside every rank's own interval, so a host-side
+        #  gloo round trip of a few hundred microseconds does not inflate a 1-ms block)
     return times, done
 
 
