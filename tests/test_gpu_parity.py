@@ -269,6 +269,35 @@ def test_burgers_ide_eval(burgers_sets, record, dtype, tag):
     eng.close()
 
 
+def test_burgers_ide_all_grid_points_persistent_tiles_f64(burgers_sets):
+    """identification on all 25600 grid points = 400 tiles on 256 compute units: the float64 register-stash kernel
+    (path 7, PDE variant with the lambda gradients) loops over tiles; against the generic kernels and the oracle"""
+    from oracle import pde
+    from pinn_native import Engine
+    r = burgers_sets(100, 10000)
+    X_star, u_star = r[5], r[6]
+    layers = [2] + [20] * 8 + [1]
+    lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
+    g = np.load(golden("burgers_ide_eval.npz"))
+    rs = np.random.RandomState(5)
+    w = g["w0"] + 0.03 * rs.standard_normal(g["w0"].size)
+    out = {}
+    for path in (7, 0):
+        eng = Engine(layers, lb, ub, pde="burgers_ide", dtype="f64")
+        eng.set_kernel_path(path)
+        eng.set_data(X_star, u_star)
+        eng.set_weights(w)
+        out[path] = eng.loss_grad()
+        again = eng.loss_grad()
+        assert again[0] == out[path][0] and np.array_equal(again[1], out[path][1])
+        eng.close()
+    lo, go, _ = pde.burgers_ide_loss_grad(w, layers, lb, ub, X_star, u_star)
+    for path in (7, 0):
+        assert abs(out[path][0] - lo) / lo < TOL["f64"]["loss"]
+        assert rel(out[path][1], go) < TOL["f64"]["grad"]
+        assert abs(out[path][1][-1] - go[-1]) < 1e-10 * abs(go[-1]) and abs(out[path][1][-2] - go[-2]) < 1e-10 * abs(go[-2])
+
+
 @pytest.mark.parametrize("tag", ["_small", ""])
 def test_burgers_ide_adam_and_lbfgs_trajectories_f64(record, tag):
     """10 Adam steps (lr 1e-3, ide_cont_burgers.py:36-39) and the 25-iteration L-BFGS trajectory of the reference's

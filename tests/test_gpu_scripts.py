@@ -155,6 +155,26 @@ def test_ide_cont_burgers_cfg3_default_schedule(tmp_path, record):
         assert v <= 0.02, (k, v, vals)
 
 
+def test_default_arithmetic_is_the_references_float64(monkeypatch):
+    """without an hp["dtype"] key the drop-in computes in float64 like the reference (utils/neuralnetwork.py:24-26), on
+    the float64 register-stash kernel; "f32" is the opt-in throughput mode"""
+    import importlib
+    import numpy as np
+    for p in (os.path.join(PKG, "utils"), os.path.join(PKG, "1d-burgers")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    monkeypatch.setattr(sys, "argv", ["inf_cont_burgers.py"])
+    inf = importlib.import_module("inf_cont_burgers")
+    from logger import Logger
+    hp = dict(json.load(open(golden("burgers_default_run.json")))["hp"], tf_epochs=0, nt_epochs=0)
+    assert "dtype" not in hp
+    X_f = np.random.RandomState(0).uniform([-1, 0], [1, 0.99], (512, 2))
+    a = inf.BurgersInformedNN(hp, Logger(hp), X_f, np.array([1.0, 0.99]), np.array([-1.0, 0.0]), nu=0.01 / np.pi)
+    assert a.compute_dtype == "f64" and a._engine.dtype == "f64" and a._engine.kernel_path() == 7
+    b = inf.BurgersInformedNN(dict(hp, dtype="f32"), Logger(hp), X_f, np.array([1.0, 0.99]), np.array([-1.0, 0.0]), nu=0.01 / np.pi)
+    assert b._engine.dtype == "f32" and b._engine.kernel_path() == 2
+
+
 def test_plotting_and_result_directory(tmp_path):
     """the scripts end like the reference's: utils/plotting.py:8-16 saveResultDir + burgersutil.py:133-206 write
     results/<stamp>-<script>/{graph.pdf, graph.png, hp.json} (+ weights.npy: the flat vector)"""
