@@ -254,7 +254,7 @@ def reference_ensemble():
 
 
 def cpu_baseline_reference(budget_threads=(8, 0)):
-    """Tier A: the reference's own inf_cont_burgers.py + utils (oracle/_ref, staged by oracle/make_ref.py)
+    """Tier A: the reference's own inf_cont_burgers.py + utils (oracle/_ref/reference_sources.tar.gz, packed by oracle/make_ref.py)
     over the torch-CPU stand-in for tensorflow, default schedule (100 Adam + 200 L-BFGS) on N_f = 10000, timed around
     NeuralNetwork.fit.  A short probe picks the better of 8 threads (what the survey measured) and torch's default."""
     script = os.path.join(ROOT, "oracle", "ref_baseline.py")

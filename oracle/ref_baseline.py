@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Tier-A CPU baseline: the REFERENCE's own 1d-burgers/inf_cont_burgers.py (staged unmodified under oracle/_ref by
-oracle/make_ref.py) executed over the torch-CPU stand-in for the `tensorflow` module (tests/ref_shims), timed.
+"""Tier-A CPU baseline: the REFERENCE's own 1d-burgers/inf_cont_burgers.py (packed unmodified into
+oracle/_ref/reference_sources.tar.gz by oracle/make_ref.py, unpacked into a scratch directory for this run) executed
+over the torch-CPU stand-in for the `tensorflow` module (tests/ref_shims), timed.
 
 TEST INFRASTRUCTURE: called by bench.py's cpu_baseline leg (as a subprocess) and by nothing in the product path.
 
@@ -17,13 +18,16 @@ import io
 import json
 import os
 import runpy
+import shutil
 import sys
+import tempfile
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-REFDIR = os.path.join(HERE, "_ref")
 SHIMS = os.path.join(ROOT, "tests", "ref_shims")
+sys.path.insert(0, ROOT)
+from oracle import make_ref  # noqa: E402
 
 
 def main():
@@ -32,9 +36,10 @@ def main():
     ap.add_argument("--nt-epochs", type=int, default=200)
     ap.add_argument("--threads", type=int, default=0, help="torch intra-op threads (0 = torch's default)")
     args = ap.parse_args()
-    if not os.path.exists(os.path.join(REFDIR, "1d-burgers", "inf_cont_burgers.py")):
-        print(json.dumps({"error": "oracle/_ref is not staged (python3 oracle/make_ref.py in the build container)"}))
+    if not make_ref.staged():
+        print(json.dumps({"error": "oracle/_ref is not built (python3 oracle/make_ref.py in the build container)"}))
         return 1
+    REFDIR = make_ref.unpack(tempfile.mkdtemp(prefix="pinn_ref_"))
     import torch
     if args.threads > 0:
         torch.set_num_threads(args.threads)
@@ -66,6 +71,8 @@ def main():
     out = {"value": hp["N_f"] * evals / timing["fit_s"], "unit": "collocation-points/s", "evals": evals,
            "fit_seconds": timing["fit_s"], "threads": torch.get_num_threads(), "host_cores": os.cpu_count(),
            "final_l2_error": float(g["error"]()), "tf_epochs": args.tf_epochs, "nt_epochs": args.nt_epochs}
+    os.chdir(ROOT)
+    shutil.rmtree(REFDIR, ignore_errors=True)
     print(json.dumps(out))
     return 0
 

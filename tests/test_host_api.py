@@ -200,11 +200,13 @@ def test_ide_cont_repair_is_whitespace_only_and_parses():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference tree (build container only)")
-def test_oracle_ref_staging_copies_the_reference_files_verbatim():
+def test_oracle_ref_archive_holds_the_reference_files_verbatim(tmp_path):
     import filecmp
     from oracle import make_ref
     assert make_ref.stage(verbose=False) and make_ref.staged()
+    make_ref.unpack(str(tmp_path))
     for rel in make_ref.FILES:
-        assert filecmp.cmp(os.path.join("/root/reference", rel), os.path.join(make_ref.DST, rel), shallow=False)
-    # staged sources never enter the history
+        assert filecmp.cmp(os.path.join("/root/reference", rel), os.path.join(str(tmp_path), rel), shallow=False)
+        assert not os.path.exists(os.path.join(make_ref.DST, rel))      # no plain copy of a reference source in the tree
+    # the archive never enters the history
     assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read()
