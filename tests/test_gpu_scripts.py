@@ -47,22 +47,41 @@ def parse(stdout):
     return rows, end
 
 
+# relative deviation of the printed losses allowed per phase: (Adam epochs 0..90, L-BFGS its <= 50, L-BFGS its <= 100)
+# (the log prints 5 significant digits: 5e-5 is its resolution).  Measured on MI355X: float64 identical in every printed
+# digit through L-BFGS iteration 100 (5 % at the end of the 200); float32 1.1e-5 over the 100 Adam epochs, 8e-3 /
+# 3.8e-2 after 50 / 100 L-BFGS iterations (13 % at the end) -- the schedule amplifies roundoff, see test_gpu_end_to_end.py
+LOG_TOL = {"f64": (1.5e-4, 1.5e-4, 1.5e-4), "f32": (1.5e-4, 3e-2, 1.2e-1)}
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_inf_cont_burgers_default_run_matches_reference_log(tmp_path, dtype):
+def test_inf_cont_burgers_default_run_matches_reference_log(tmp_path, record, dtype):
     g = json.load(open(golden("burgers_default_run.json")))
+    b = json.load(open(golden("burgers_band.json")))
     hp = dict(g["hp"], dtype=dtype)
     out = run_script(os.path.join("1d-burgers", "inf_cont_burgers.py"), hp, tmp_path)
     assert "Training started" in out and "-- Starting Adam optimization --" in out
     rows, end = parse(out)
     ref, _ = parse("\n".join(g["lines"]))
     assert [(r[0], r[1]) for r in rows] == [(r[0], r[1]) for r in ref]      # same lines, same epochs
+    dev = {"adam": 0.0, "lbfgs50": 0.0, "lbfgs100": 0.0, "lbfgs_all": 0.0}
     for (kind, ep, loss), (_, _, loss_ref) in zip(rows, ref):
-        if dtype == "f64" and (kind == "tf_epoch" or ep <= 100):
-            assert abs(loss - loss_ref) <= 1.5e-4 * loss_ref, (kind, ep, loss, loss_ref)
-        if dtype == "f32" and kind == "tf_epoch" and ep <= 20:
-            assert abs(loss - loss_ref) <= 2e-3 * loss_ref, (kind, ep, loss, loss_ref)
+        d = abs(loss - loss_ref) / loss_ref
+        if kind == "tf_epoch":
+            dev["adam"] = max(dev["adam"], d)
+        else:
+            if ep <= 50:
+                dev["lbfgs50"] = max(dev["lbfgs50"], d)
+            if ep <= 100:
+                dev["lbfgs100"] = max(dev["lbfgs100"], d)
+            dev["lbfgs_all"] = max(dev["lbfgs_all"], d)
+    record(dtype=dtype, final_error=end[1], **dev)
+    ta, t50, t100 = LOG_TOL[dtype]
+    assert dev["adam"] <= ta and dev["lbfgs50"] <= t50 and dev["lbfgs100"] <= t100, dev
     assert end is not None and end[0] == 300
-    assert 0.24 <= end[1] <= 0.31, end                                      # reference: 2.6564e-01
+    from conftest import ensemble_accepts
+    ok, med, radius = ensemble_accepts([v["final_error"] for v in b["runs"].values()], end[1])
+    assert ok, (end, med, radius)                                           # reference: 2.6564e-01
 
 
 def test_ide_cont_burgers_run_matches_reference_log(tmp_path):
