@@ -323,38 +323,44 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
           for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
         }
       }
-      // layer-(d-1) output channels, rotated: the A operands of the weight gradient
-      double inT[4][5];
-#pragma unroll
-      for (int m = 0; m < 5; ++m) {
-        double a, zp, zq, zr;
-        if (d - 1 == 0) {
-          const int f = 4 * m + s;
-          a = a0[m]; zp = sx * wl[nd.off_w[0] + f]; zq = st * wl[nd.off_w[0] + FW + f]; zr = 0.0;
-        } else {
-          a = agd_get(stash[d - 1][m][0]); zp = agd_get(stash[d - 1][m][1]);
-          zq = agd_get(stash[d - 1][m][2]); zr = agd_get(stash[d - 1][m][3]);
-        }
-        double h, p, qq, r;
-        channels_d(a, zp, zq, zr, h, p, qq, r);
-        inT[0][m] = lane_fetch(h, rot4); inT[1][m] = lane_fetch(p, rot4);
-        inT[2][m] = lane_fetch(qq, rot4); inT[3][m] = lane_fetch(r, rot4);
-      }
-      // dW_d[4m + i][4n + j] and db_d[4n + j] (row 0 of the ones in-group)
+      // dW_d[4m + i][4n + j]: the A operands are the layer-(d-1) output channels, rotated -- produced one in-group
+      // ahead of the matrix instructions that consume them (20 values live instead of 40: the kernel sits at the
+      // 256-VGPR limit, and with all of them live hipcc sank the accumulator fetches next to their uses)
       const int base = 5 + (d - 1) * 30;
+#define PINN_ROTATED_INPUTS(M, O4)                                                                          \
+  do {                                                                                                      \
+    double a_, zp_, zq_, zr_;                                                                               \
+    if (d - 1 == 0) {                                                                                       \
+      const int f_ = 4 * (M) + s;                                                                           \
+      a_ = a0[M]; zp_ = sx * wl[nd.off_w[0] + f_]; zq_ = st * wl[nd.off_w[0] + FW + f_]; zr_ = 0.0;         \
+    } else {                                                                                                \
+      a_ = agd_get(stash[d - 1][M][0]); zp_ = agd_get(stash[d - 1][M][1]);                                  \
+      zq_ = agd_get(stash[d - 1][M][2]); zr_ = agd_get(stash[d - 1][M][3]);                                 \
+    }                                                                                                       \
+    double h_, p_, q_, r_;                                                                                  \
+    channels_d(a_, zp_, zq_, zr_, h_, p_, q_, r_);                                                          \
+    O4[0] = lane_fetch(h_, rot4); O4[1] = lane_fetch(p_, rot4);                                             \
+    O4[2] = lane_fetch(q_, rot4); O4[3] = lane_fetch(r_, rot4);                                             \
+  } while (0)
+      double cur[4];
+      PINN_ROTATED_INPUTS(0, cur);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {          // five independent accumulator chains per in-group
-        double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[5];
+        double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[5], nxt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int n = 0; n < 5; ++n) old[n] = grad_fetch(base + m * 5 + n);
+        if (m + 1 < 5) PINN_ROTATED_INPUTS((m + 1 < 5 ? m + 1 : 4), nxt);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-          for (int n = 0; n < 5; ++n) D[n] = mfma444(inT[c][m], zbT[c][n], D[n]);
+          for (int n = 0; n < 5; ++n) D[n] = mfma444(cur[c], zbT[c][n], D[n]);
         }
 #pragma unroll
         for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + m * 5 + n);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
       }
+#undef PINN_ROTATED_INPUTS
       {
         double D[5], old[5];
 #pragma unroll
@@ -396,20 +402,26 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
 
   // -------------------------------------------------------------------- one gradient row per workgroup
   {
-    const double t0 = wave_sum(l_res), t1 = wave_sum(l_dat), t2 = wave_sum(dl0), t3 = wave_sum(dl1);
+    // row_index[e]: flat parameter index of entry e of the block list (-1: padding), built once on the host;
+    // fetched first so that its (cold) latency hides under the wave sums and the two barriers
+    constexpr int NE = NBLK * 16, NIT = (NE + 255) / 256;
+    int idx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 256 * it;
+      idx[it] = e < NE ? row_index[e] : -1;
+    }
+    const double t0 = wave_sum(l_res), t1 = wave_sum(l_dat);
+    const double t2 = PDE == 1 ? wave_sum(dl0) : 0.0, t3 = PDE == 1 ? wave_sum(dl1) : 0.0;
     __syncthreads();                                   // every wave's accumulators are final
     double* const scal = wl;                           // the weight copy is dead: 4 x 4 loss / lambda partials
     if (lane == 0) { scal[wave * 4 + 0] = t0; scal[wave * 4 + 1] = t1; scal[wave * 4 + 2] = t2; scal[wave * 4 + 3] = t3; }
     __syncthreads();
     double* __restrict__ row = part + (size_t)blockIdx.x * R;
-    // row_index[e]: flat parameter index of entry e of the block list (-1: padding), built once on the host
-    constexpr int NE = NBLK * 16, NIT = (NE + 255) / 256;
-    int idx[NIT];
     double v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + 256 * it;
-      idx[it] = e < NE ? row_index[e] : -1;
       const int ee = e < NE ? e : 0;
       v[it] = ((gacc_all[ee] + gacc_all[NE + ee]) + gacc_all[2 * NE + ee]) + gacc_all[3 * NE + ee];
     }
