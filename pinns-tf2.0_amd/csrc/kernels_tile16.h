@@ -124,16 +124,43 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
           bj[r] = j < W ? bl[j] : real(0);
         }
         acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+        const int ja = 16 * ct + m;                               // A[m = feature 16ct+m][k]
+        if constexpr (WLDS) {
 #pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-          const int k = 4 * ks + g;
-          const int ja = 16 * ct + m;                             // A[m = feature 16ct+m][k]
-          const real a = WLDS ? wb[k * WLD + ja] : ((k < W && ja < W) ? Wl[k * W + ja] : real(0));
-          const V4 b = Tin[k * PD + m];                           // B[k][n = point m]
-          a0 = TR::mfma(a, b.x, a0);
-          a1 = TR::mfma(a, b.y, a1);
-          a2 = TR::mfma(a, b.z, a2);
-          a3 = TR::mfma(a, b.w, a3);
+          for (int ks = 0; ks < ksteps; ++ks) {
+            const int k = 4 * ks + g;
+            const real a = wb[k * WLD + ja];
+            const V4 b = Tin[k * PD + m];                         // B[k][n = point m]
+            a0 = TR::mfma(a, b.x, a0);
+            a1 = TR::mfma(a, b.y, a1);
+            a2 = TR::mfma(a, b.z, a2);
+            a3 = TR::mfma(a, b.w, a3);
+          }
+        } else {
+          // weights straight from L2: the A operands of a chunk of four k-steps are fetched one chunk ahead, so their
+          // latency (several hundred cycles) hides under the 16 matrix instructions of the chunk in flight instead
+          // of stalling every chunk.  A last partial chunk runs on zero weights and the zero rows k >= W of the tile.
+          const int nchunks = (ksteps + 3) >> 2;
+          real wc[4], wn[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int k = 4 * u + g; wc[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0); }
+          for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int k = 4 * (4 * (c + 1) + u) + g;
+              wn[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const V4 b = Tin[(4 * (4 * c + u) + g) * PD + m];
+              a0 = TR::mfma(wc[u], b.x, a0);
+              a1 = TR::mfma(wc[u], b.y, a1);
+              a2 = TR::mfma(wc[u], b.z, a2);
+              a3 = TR::mfma(wc[u], b.w, a3);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wc[u] = wn[u];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -321,15 +348,40 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
           sk[r] = k < W ? S[((size_t)(d - 1) * W + k) * s_pad + lp0 + m] : V4{0, 0, 0, 0};
         }
         acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+        const int k = 16 * kt + m;
+        if constexpr (WLDS) {
 #pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-          const int jj = 4 * ks + g, k = 16 * kt + m;
-          const real a = WLDS ? wt[k * TLD + jj] : ((k < W && jj < W) ? Wd[k * W + jj] : real(0));
-          const V4 b = Bcur[jj * PD + m];
-          a0 = TR::mfma(a, b.x, a0);
-          a1 = TR::mfma(a, b.y, a1);
-          a2 = TR::mfma(a, b.z, a2);
-          a3 = TR::mfma(a, b.w, a3);
+          for (int ks = 0; ks < ksteps; ++ks) {
+            const int jj = 4 * ks + g;
+            const real a = wt[k * TLD + jj];
+            const V4 b = Bcur[jj * PD + m];
+            a0 = TR::mfma(a, b.x, a0);
+            a1 = TR::mfma(a, b.y, a1);
+            a2 = TR::mfma(a, b.z, a2);
+            a3 = TR::mfma(a, b.w, a3);
+          }
+        } else {                              // weights from L2, fetched one chunk of four k-steps ahead (see k_t16_fwd)
+          const int nchunks = (ksteps + 3) >> 2;
+          real wc[4], wn[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int jj = 4 * u + g; wc[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0); }
+          for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int jj = 4 * (4 * (c + 1) + u) + g;
+              wn[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const V4 b = Bcur[(4 * (4 * c + u) + g) * PD + m];
+              a0 = TR::mfma(wc[u], b.x, a0);
+              a1 = TR::mfma(wc[u], b.y, a1);
+              a2 = TR::mfma(wc[u], b.z, a2);
+              a3 = TR::mfma(wc[u], b.w, a3);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wc[u] = wn[u];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
