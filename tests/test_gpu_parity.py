@@ -511,3 +511,25 @@ def test_burgers_ragged_and_tiny_sets(burgers_sets, dtype, N_u, N_f):
             go = grad                                # first available path is the yardstick
         assert rel(grad, go) < tol["grad"] * 3, path
         eng.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_residual_at_arbitrary_points_matches_stored_set_and_oracle(burgers_sets, dtype):
+    """pinn_residual_at (f_model(X) at caller-supplied points, ide_cont_burgers.py:169-172): ragged sizes (1, 65, 1000
+    points), the empty set, equality with pinn_residual on the stored collocation set, and the oracle"""
+    from oracle import pde
+    g = np.load(golden("burgers_eval_small.npz"))
+    eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, 64, 2048, dtype)
+    rs = np.random.RandomState(2)
+    w = g["w0"] + 0.05 * rs.standard_normal(g["w0"].size)
+    eng.set_weights(w)
+    f_set = eng.residual()
+    tol = 1e-11 if dtype == "f64" else 5e-5
+    for n in (1, 65, 1000):
+        f = eng.residual_at(X_f[:n])
+        assert f.shape == (n, 1)
+        assert np.max(np.abs(f - f_set[:n])) <= tol * max(np.max(np.abs(f_set)), 1.0)
+    assert eng.residual_at(np.zeros((0, 2))).shape == (0, 1)
+    _, _, ex = pde.burgers_loss_grad(w, layers, lb, ub, X_f, X_u, u, NU)
+    assert np.max(np.abs(eng.residual_at(X_f) - ex["f"])) <= tol * max(np.max(np.abs(ex["f"])), 1.0)
+    eng.close()
