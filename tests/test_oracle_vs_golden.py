@@ -303,6 +303,14 @@ def test_gauss_legendre_butcher_conditions(q):
     assert np.max(np.abs(b[:, None] * A + (b[:, None] * A).T - np.outer(b, b))) < 1e-15   # symplectic
     if q == 2:
         assert abs(A[0, 1] - (0.25 - np.sqrt(3.0) / 6.0)) < 1e-15
+    if q == 3:        # textbook known-answer: the 3-stage, order-6 Gauss method (Hairer & Wanner, Solving ODEs II, IV.5)
+        r15 = np.sqrt(15.0)
+        A3 = np.array([[5 / 36, 2 / 9 - r15 / 15, 5 / 36 - r15 / 30],
+                       [5 / 36 + r15 / 24, 2 / 9, 5 / 36 - r15 / 24],
+                       [5 / 36 + r15 / 30, 2 / 9 + r15 / 15, 5 / 36]])
+        assert np.max(np.abs(A - A3)) < 1e-15
+        assert np.max(np.abs(b - np.array([5 / 18, 4 / 9, 5 / 18]))) < 1e-15
+        assert np.max(np.abs(c - np.array([0.5 - r15 / 10, 0.5, 0.5 + r15 / 10]))) < 1e-15
     A2, b2, c2 = irk.gauss_legendre_butcher(q)
     assert np.max(np.abs(A - A2)) < 1e-13 and np.max(np.abs(b - b2)) < 1e-13 and np.max(np.abs(c - c2)) < 1e-13
 
