@@ -1161,16 +1161,17 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
       return PINN_EHIP;
     c->lb_cap_corr = n_corr;
   }
-  HIPCHK(hipMemsetAsync(c->lb_S, 0, (size_t)M1 * n * 8, c->stream));   // unused ring slots must read as finite
-  HIPCHK(hipMemsetAsync(c->lb_Y, 0, (size_t)M1 * n * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_cs, 0, (size_t)M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_cy, 0, (size_t)M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_SY, 0, (size_t)2 * M1 * M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_YY, 0, (size_t)2 * M1 * M1 * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_ro, 0, (size_t)2 * M1 * 8, c->stream));
+  {  // unused ring slots must read as finite; Gram matrices, coefficients, dots and the extra record start at zero
+    static_assert(sizeof(LbcExtra) % 8 == 0, "LbcExtra is cleared as doubles");
+    ZeroList zl{};
+    auto add = [&](void* p, size_t doubles) { zl.p[zl.count] = (double*)p; zl.n[zl.count] = doubles; zl.count++; };
+    add(c->lb_S, (size_t)M1 * n); add(c->lb_Y, (size_t)M1 * n); add(c->lb_cs, M1); add(c->lb_cy, M1);
+    add(c->lb_SY, (size_t)2 * M1 * M1); add(c->lb_YY, (size_t)2 * M1 * M1); add(c->lb_ro, (size_t)2 * M1);
+    add(c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL)); add(c->lb_ex, sizeof(LbcExtra) / 8);
+    hipLaunchKernelGGL(k_zero_list, dim3(256), dim3(256), 0, c->stream, zl);
+    HIPCHK(hipGetLastError());
+  }
   c->lb_flip = 0;
-  HIPCHK(hipMemsetAsync(c->lb_dots, 0, (size_t)(5 * M1 + LBC_NSCAL) * 8, c->stream));
-  HIPCHK(hipMemsetAsync(c->lb_ex, 0, sizeof(LbcExtra), c->stream));
   if (max_iter + 1 > c->lb_cap_log) {
     if (dev_alloc(&c->lb_log_loss, (size_t)(max_iter + 1) * 8) ||
         dev_alloc(&c->lb_log_iter, (size_t)(max_iter + 1) * 4))

@@ -316,6 +316,23 @@ struct LbcExtra {
   double cg, gtd;
 };
 
+// pinn_lbfgs_begin clears nine device arrays (ring buffers, Gram matrices, coefficient vectors): one launch instead of
+// nine hipMemsetAsync launches (each costs a launch floor, ~40 us together -- visible in the driver's 20-step blocks)
+struct ZeroList {
+  double* p[10];
+  unsigned long long n[10];     // doubles
+  int count;
+};
+__global__ __launch_bounds__(256) void k_zero_list(ZeroList zl) {
+  for (int a = 0; a < zl.count; ++a) {
+    double* __restrict__ p = zl.p[a];
+    const unsigned long long n = zl.n[a];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * 256)
+      p[i] = 0.0;
+  }
+}
+
 constexpr int LBC_THREADS = 1024;  // k_lbc_coef: 16 waves stage the Gram matrices, wave 0 runs the recursion
 constexpr int LBC_ROWS = 4;        // ceil(62 / 16) matrix rows per thread
 constexpr int LBD_THREADS = 1024;  // k_lbc_dots: n = 3021 is three strides of a 1024-thread block
