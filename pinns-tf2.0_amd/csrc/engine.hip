@@ -206,7 +206,21 @@ static bool t16_lds_weights(const pinn_ctx* c, int pts) {
 }
 static int t16_wgs(const pinn_ctx* c, int pts) {
   const int g = pts / 16;
-  const int per_cu = (c->nd.width <= 64 && c->dtype != PINN_F64 && g <= 3 * c->n_cu) ? 3 : 2;
+  int per_cu = (c->nd.width <= 64 && c->dtype != PINN_F64 && g <= 3 * c->n_cu) ? 3 : 2;
+  // ... but never more workgroups than are resident at once: a persistent grid larger than what the CUs' LDS admits
+  // runs in two batches whose group counts round up separately (width 100: 1250 groups on 512 workgroups of which
+  // 256 fit = 3 + 3 group times instead of 5).  Widths > 64 take 140-147 KB per workgroup: one per CU.
+  const size_t rs = c->dtype == PINN_F64 ? 8 : 4;
+  size_t lds;
+  if (c->nd.width > 64) {
+    const bool wl = rs == 4;
+    lds = t16_fwd_lds<8>(rs, wl) > t16_bwd_lds<8>(rs, wl) ? t16_fwd_lds<8>(rs, wl) : t16_bwd_lds<8>(rs, wl);
+  } else {
+    const bool wl = t16_lds_weights(c, pts);
+    lds = t16_fwd_lds<4>(rs, wl) > t16_bwd_lds<4>(rs, wl) ? t16_fwd_lds<4>(rs, wl) : t16_bwd_lds<4>(rs, wl);
+  }
+  const int fit = (int)((size_t)160 * 1024 / lds) > 0 ? (int)((size_t)160 * 1024 / lds) : 1;
+  if (per_cu > fit) per_cu = fit;
   const int cap = per_cu * c->n_cu;
   return g < cap ? g : cap;
 }
