@@ -306,19 +306,29 @@ def cpu_baseline_port(X_f, X_u, u, lb, ub, w0, budget_s=6.0):
 
 def pmc_traffic(dtype, n_f_total, world, path):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-    are collected in separate runs, so they cannot be read live here); default workload only, null otherwise."""
-    if n_f_total != 10000 or world != 1:
+    are collected in separate runs, so they cannot be read live here): the headline workload (N_f = 10000) and the
+    N_f = 10^6 leg on one GPU; null otherwise."""
+    if world != 1 or n_f_total not in (10000, 1000000):
         return None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as fh:
-                j = json.load(fh)
-            key = "traffic_bytes_per_launch" if dtype == "f32" else "traffic_bytes_per_launch_f64"
-            if j.get(key) is not None and j.get("kernel_path_" + dtype, 2 if dtype == "f32" else None) in (path, None):
-                return float(j[key])
-        except Exception:
-            continue
-    return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            j = json.load(fh)
+        if j.get("kernel_path_" + dtype) != path:
+            return None
+        if n_f_total == 1000000:
+            return float(j["nf1e6"]["traffic_bytes_per_launch_" + dtype])
+        return float(j["traffic_bytes_per_launch" if dtype == "f32" else "traffic_bytes_per_launch_f64"])
+    except Exception:
+        return None
+
+
+def with_traffic(leg_dict, world):
+    """attach the PMC traffic (and the HBM rate it implies) to a leg's roofline"""
+    rf = leg_dict["roofline"]
+    rf["traffic"] = pmc_traffic(leg_dict["dtype"], leg_dict["n_f_total"], world, leg_dict["kernel_path"])
+    if rf["traffic"] and rf["avg_launch_ms"]:
+        rf["hbm_gbps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+    return leg_dict
 
 
 def main():
@@ -376,10 +386,7 @@ def main():
     # ---- headline leg ---------------------------------------------------------------------------------------
     main_leg, eng = leg("headline", args.dtype, device, data, w0, wd, k_adam, k_lbfgs, args.warmup, args.kernel_path,
                         init_comm=init_comm)
-    main_leg["roofline"]["traffic"] = pmc_traffic(args.dtype, n_f_total, world, main_leg["kernel_path"])
-    rf = main_leg["roofline"]
-    if rf["traffic"] and rf["avg_launch_ms"]:
-        rf["hbm_gbps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
+    with_traffic(main_leg, world)
     replicas_identical = None
     if dist is not None:
         import hashlib
@@ -403,7 +410,7 @@ def main():
     if args.dtype == "f32" and not args.no_f64_leg:
         f64_leg, e64 = leg("float64", "f64", device, data, w0, wd, k_adam, k_lbfgs, min(args.warmup, 9), spin=False,
                            init_comm=init_comm)
-        f64_leg["roofline"]["traffic"] = pmc_traffic("f64", n_f_total, world, f64_leg["kernel_path"])
+        with_traffic(f64_leg, world)
         if not args.no_final_error:
             if n_f_total != 10000:
                 from pinn_native.parallel import attach_shards
@@ -417,6 +424,7 @@ def main():
         _, _, data5 = dataset(1000000)
         cfg5, e5 = leg("cfg5", args.dtype, device, data5, w0, wd, k_adam, k_lbfgs, min(args.warmup, 6),
                        args.kernel_path, spin=False, init_comm=init_comm)
+        with_traffic(cfg5, world)
         e5.close()
 
     # every rank empties its C stdio buffer (RCCL's banner) before rank 0 prints: the JSON line stays the last line
