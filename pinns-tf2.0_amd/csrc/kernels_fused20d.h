@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
   const int pr = i4 * FW + s;              // reverse pattern:  W[4m + i4][4n + s]
   const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   // lane-index rotation by two bits (bpermute address)
   double* const gacc = gacc_all + wave * (NBLK * 16);
-  const int ge = s * 4 + i4;               // this lane's entry of a gradient block (valid where (lane >> 2) & 3 == 0)
+  const int ge = s * 4 + i4;               // this lane's entry (i, j) of a gradient block; shared by its four b-lanes
 
   // ---- flat weight vector -> LDS by asynchronous LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no
   // registers; the engine pads the vector's allocation to whole pieces), gradient accumulators <- 0 meanwhile
