@@ -137,11 +137,13 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
   for (int k = 0; k < FW; ++k) {
     const float a = ao[k >> 2][k & 3];
     acc_own[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].x, acc_own[0], 0, 0, 0);
+    side(4 * k);
     acc_own[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].y, acc_own[1], 0, 0, 0);
-    side(2 * k);
+    side(4 * k + 1);
     acc_own[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].z, acc_own[2], 0, 0, 0);
+    side(4 * k + 2);
     acc_own[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].w, acc_own[3], 0, 0, 0);
-    side(2 * k + 1);
+    side(4 * k + 3);
   }
   // group 4, one channel per wave: uniform branch, only the selected 20 MFMAs execute; two
   // accumulators so that consecutive MFMAs do not depend on each other.  (Running this unit
@@ -217,19 +219,33 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
   const float inv_nf = (float)sd.inv_nf, inv_nu = (float)sd.inv_nu;
 
   // accumulators that live across tiles
-  acc4 dw[H][2];          // dw[d][0..1], d = 1..H-1: this wave's 16x16 tile of dW_d, split over two
-                          // accumulators (channels h,q / p,r) so consecutive MFMAs never depend
+  // dW_d (+ db_d as row 20) = IN^T . ZB over the tile's 256 (point,channel) rows, as
+  //   dwm[d]: the 16x16 block (k < 16, j < 16) on v_mfma_f32_16x16x4 -- this wave's quarter of the rows
+  //           (points 16q + 4w .. +3 of every lane group q), 16 MFMAs;
+  //   dwf[d]: the fringe (k = 16..20 or j = 16..19; 164 entries) as 14 of the 16 independent 4x4
+  //           blocks of v_mfma_f32_4x4x1_16B, one (point,channel) row per instruction -- this wave's
+  //           16 points, 64 MFMAs.
+  // (Padding the fringe out to three more 16x16 tiles, one tile per wave, cost 64 x 32-cycle
+  // MFMAs per wave and layer; this split costs 16 x 32 + 64 x 8.)  The four waves' partial sums meet
+  // once per kernel in the epilogue.
+  acc4 dwm[H], dwf[H];
 #pragma unroll
-  for (int d = 0; d < H; ++d) dw[d][0] = dw[d][1] = acc4{0, 0, 0, 0};
+  for (int d = 0; d < H; ++d) dwm[d] = dwf[d] = acc4{0, 0, 0, 0};
   float g0x[FF], g0t[FF], g0b[FF], gH[FF];
 #pragma unroll
   for (int jj = 0; jj < FF; ++jj) g0x[jj] = g0t[jj] = g0b[jj] = gH[jj] = 0.0f;
   float gHb = 0.0f, l_res = 0.0f, l_dat = 0.0f, dl0 = 0.0f, dl1 = 0.0f;
 
-  const int ti = wave >> 1, tj = wave & 1;                    // this wave's 16x16 tile of dW
-  const int fa = min(16 * ti + (lane & 15), FW);              // A row: input feature (20 = ones)
-  const int fb = min(16 * tj + (lane & 15), FW - 1);          // B column: output feature
-  const int kq = (lane >> 4) * 16;                            // this lane group's 16 points
+  // main block operands: A row = input feature lane%16, B column = output feature lane%16,
+  // lane group q = lane/16 supplies point 16q + 4w + jj at step jj
+  const int mrow = (lane & 15) * RS4 + (lane >> 4) * 16 + 4 * wave;
+  // fringe block b = lane/4 -> (input-feature group kg, output-feature group jg):
+  //   b 0..3: (4, b)   b 4..7: (5 = ones row, b-4)   b 8..11: (b-8, 4)   b 12: (4, 4)   b 13..15: (5, 4)
+  const int fblk = lane >> 2;
+  const int fkg = fblk < 4 ? 4 : fblk < 8 ? 5 : fblk < 12 ? fblk - 8 : fblk == 12 ? 4 : 5;
+  const int fjg = fblk < 8 ? (fblk & 3) : 4;
+  const int farow = min(4 * fkg + (lane & 3), FW) * RS4 + 16 * wave;     // rows past the ones row repeat it
+  const int fbrow = (4 * fjg + (lane & 3)) * RS4 + 16 * wave;
   const int qw = 4 * lane + wave;                             // float index of (point, channel = wave) in a Q row
   STAMP(1);
   bool image_pending = true;
@@ -364,25 +380,28 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       v4f zin[FW];
 #pragma unroll
       for (int j = 0; j < FW; ++j) zin[j] = ZB[j * RS4 + lane];
-      v4f a4[2], b4[2];                        // 16x16x4 operand ring: group j in slot j & 1
-      a4[0] = IN[fa * RS4 + kq + 0]; b4[0] = ZB[fb * RS4 + kq + 0];
-      a4[1] = IN[fa * RS4 + kq + 1]; b4[1] = ZB[fb * RS4 + kq + 1];
+      // operand rings, refilled two steps ahead: main block step jj = 0..3 (4 MFMAs each, one per
+      // channel), fringe step p = 0..15 (one point, 4 MFMAs)
+      v4f ma[2], mb[2], fa4[2], fb4[2];
+      ma[0] = IN[mrow + 0]; mb[0] = ZB[mrow + 0];
+      ma[1] = IN[mrow + 1]; mb[1] = ZB[mrow + 1];
+      fa4[0] = IN[farow + 0]; fb4[0] = ZB[fbrow + 0];
+      fa4[1] = IN[farow + 1]; fb4[1] = ZB[fbrow + 1];
       acc4 acc_own[4], acc_g4 = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc_own[c] = acc4{0, 0, 0, 0};
-      acc4 acc0 = dw[d][0], acc1 = dw[d][1];
-      auto dw_mfma = [&](int m) {              // m = 0..63: group j = m/4, channel m%4
-        const int j = m >> 2, c = m & 3;
-        const v4f a = a4[j & 1], b = b4[j & 1];
-        if (c == 0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc0, 0, 0, 0);
-        if (c == 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc1, 0, 0, 0);
-        if (c == 2) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc0, 0, 0, 0);
-        if (c == 3) {
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc1, 0, 0, 0);
-          if (j + 2 < 16) {                    // refill this ring slot two groups ahead
-            a4[j & 1] = IN[fa * RS4 + kq + j + 2];
-            b4[j & 1] = ZB[fb * RS4 + kq + j + 2];
-          }
+      acc4 accm = dwm[d], accf = dwf[d];
+      auto dw_mfma = [&](int s) {              // s = 0..79, one after every own-group GEMV MFMA
+        if (s % 5 == 4) {                      // 16 main-block MFMAs: step jj = m/4, channel m%4
+          const int m = s / 5, jj = m >> 2, c = m & 3;
+          const v4f a = ma[jj & 1], b = mb[jj & 1];
+          accm = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], accm, 0, 0, 0);
+          if (c == 3 && jj + 2 < 4) { ma[jj & 1] = IN[mrow + jj + 2]; mb[jj & 1] = ZB[mrow + jj + 2]; }
+        } else {                               // 64 fringe MFMAs: point p = m/4, channel m%4
+          const int m = s - s / 5, p = m >> 2, c = m & 3;
+          const v4f a = fa4[p & 1], b = fb4[p & 1];
+          accf = __builtin_amdgcn_mfma_f32_4x4x1f32(a[c], b[c], accf, 0, 0, 0);
+          if (c == 3 && p + 2 < 16) { fa4[p & 1] = IN[farow + p + 2]; fb4[p & 1] = ZB[fbrow + p + 2]; }
         }
       };
       gemv_mfma(acc_own, acc_g4, wimg, wave, lane, zin,
@@ -390,10 +409,8 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
 #pragma unroll
                   for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = g[i];
                 },
-                [&](int slot) { dw_mfma(slot); });   // slots 0..39
-#pragma unroll
-      for (int m = 2 * FW; m < 64; ++m) dw_mfma(m);
-      dw[d][0] = acc0; dw[d][1] = acc1;
+                [&](int slot) { dw_mfma(slot); });   // slots 0..79
+      dwm[d] = accm; dwf[d] = accf;
       if (d == 4) STAMP(30);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) ob[kk] = v4f{acc_own[0][kk], acc_own[1][kk], acc_own[2][kk], acc_own[3][kk]};
@@ -421,6 +438,15 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     // the two halves meet through one bpermute.  (A DPP butterfly per value costs ~3x the issue slots.)
     constexpr int NV = 25, RSF = 68;                 // rows; padded row stride in floats (16-B aligned)
     float* __restrict__ red = reinterpret_cast<float*>(xb) + wave * (NV * RSF);
+    // behind the four waves' row areas: the weight-gradient partials, [wave][layer][main|fringe][lane]
+    constexpr int PSW = (H - 1) * 2 * 64;            // float4 per wave
+    v4f* const psum = xb + NV * RSF;
+    static_assert(NV * RSF + 4 * PSW <= 4 * BUFV, "partials fit in the exchange area");
+#pragma unroll
+    for (int d = 1; d < H; ++d) {
+      psum[wave * PSW + ((d - 1) * 2 + 0) * 64 + lane] = dwm[d];
+      psum[wave * PSW + ((d - 1) * 2 + 1) * 64 + lane] = dwf[d];
+    }
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) {
       red[(0 + kk) * RSF + lane] = g0x[kk];
@@ -454,16 +480,26 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       if (PDE == 1 && lane == 24) row[nd.n_net + 1] = tot;
     }
     STAMP(31);
-    // dW / db tiles: lane (l & 15) holds output feature jg, VGPR r holds input feature ig (20 = bias
-    // row); b_d sits right behind W_d in the flat layout, so one offset serves both
-    const int jg = 16 * tj + (lane & 15);
+    // dW / db: the four waves' partial blocks (published above) are added up layer by layer, wave w
+    // taking layers w+1 and w+5.  b_d sits right behind W_d in the flat layout, so input-feature row
+    // 20 (the ones row) lands on the bias.
+    lds_barrier();
+    const int km = 4 * (lane >> 4), jm = lane & 15;              // main block: VGPR r -> input feature km + r
+    const int kf = 4 * fkg, jf = 4 * fjg + (lane & 3);           // fringe block: VGPR r -> input feature kf + r
+    const bool okf = fblk <= 13;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ig = 16 * ti + (lane >> 4) * 4 + r;
-      if (jg < FW && ig <= FW) {
-        float* __restrict__ dst = row + nd.off_w[1] + ig * FW + jg;
+    for (int half = 0; half < 2; ++half) {
+      const int d1 = wave + 4 * half;
+      if (d1 < H - 1) {
+        float* __restrict__ dst = row + nd.off_w[1] + d1 * (FW * FW + FW);
+        const v4f* __restrict__ src = psum + (d1 * 2) * 64 + lane;
+        const v4f m4 = (src[0 * PSW] + src[1 * PSW]) + (src[2 * PSW] + src[3 * PSW]);
+        const v4f f4 = (src[0 * PSW + 64] + src[1 * PSW + 64]) + (src[2 * PSW + 64] + src[3 * PSW + 64]);
 #pragma unroll
-        for (int d = 1; d < H; ++d) dst[(d - 1) * (FW * FW + FW)] = dw[d][0][r] + dw[d][1][r];
+        for (int r = 0; r < 4; ++r) {
+          dst[(km + r) * FW + jm] = m4[r];
+          if (okf && kf + r <= FW) dst[(kf + r) * FW + jf] = f4[r];
+        }
       }
     }
   }
