@@ -64,6 +64,14 @@ __device__ __forceinline__ v4f agpr_get4(const v4f a) {
   return v4f{agpr_get(a.x), agpr_get(a.y), agpr_get(a.z), agpr_get(a.w)};
 }
 
+// one 1-KiB piece global -> LDS (lane i: 16 bytes from g to lds_piece + 16 i), invisible to the compiler
+__device__ __forceinline__ void lds_dma_b128(const float* g, float* lds_piece) {
+  const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_piece;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(base) : "memory", "m0");
+}
+// makes the compiler wait for a loaded value here
+__device__ __forceinline__ void consume4(v4f& v) { asm volatile("" : "+v"(v)); }
+
 // tanh(x) = 1 - 2 / (1 + e^{2x}); absolute error ~1 ulp of 1.0 (cf. tanh_bf)
 __device__ __forceinline__ float tanh_r5(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
@@ -96,7 +104,10 @@ __device__ __forceinline__ v4f preact_adjoint4(const v4f s, const v4f ob) {
 constexpr int WIMG = 820;
 
 // padded to whole 1-KiB pieces: the image is brought into LDS by asynchronous LDS-DMA
-inline size_t fused20m_image_floats(int n_hidden) { return ((size_t)(n_hidden - 1) * WIMG + 255) / 256 * 256; }
+// (four pieces per round, one per wave: every wave issues the same, compile-time number of DMA
+// instructions, so the compiler's vmcnt bookkeeping stays exact and waiting for an earlier plain load
+// does not wait for the image)
+inline size_t fused20m_image_floats(int n_hidden) { return ((size_t)(n_hidden - 1) * WIMG + 1023) / 1024 * 1024; }
 inline size_t fused20m_lds_bytes(int n_hidden) {
   return fused20m_image_floats(n_hidden) * 4 + (size_t)(4 * FROWS + 4) * 65 * 16;
 }
@@ -124,15 +135,20 @@ typedef float acc4 __attribute__((ext_vector_type(4)));
 // acc_g4[i]     += sum_k P[(16+i)][k]    in_wave[k]            -- 20 MFMAs (channel = wave index)
 // P = 20x20 row-major pattern matrix in LDS (W^T forward, W reverse); in = 20 float4 tiles rows.
 // g4_ready(acc_g4) is called as soon as the group-4 unit is complete (the caller publishes it).
-template <typename G4, typename SIDE>
-__device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, const float* __restrict__ P,
-                                          const int wave, const int lane, const v4f (&in)[FW],
-                                          G4 g4_ready, SIDE side) {
+// this lane's weight patterns of a 20x20 pattern matrix P (LDS image, or the global image for the
+// very first layer): ao = rows of the wave's own group, ag = rows of group 4
+__device__ __forceinline__ void load_patterns(const float* __restrict__ P, const int wave, const int lane,
+                                              v4f (&ao)[5], v4f (&ag)[5]) {
   const v4f* __restrict__ po = reinterpret_cast<const v4f*>(P + (4 * wave + (lane & 3)) * FW);
   const v4f* __restrict__ pg = reinterpret_cast<const v4f*>(P + (16 + (lane & 3)) * FW);
-  v4f ao[5], ag[5];
 #pragma unroll
   for (int m = 0; m < 5; ++m) { ao[m] = po[m]; ag[m] = pg[m]; }
+}
+
+template <typename G4, typename SIDE>
+__device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, const v4f (&ao)[5], const v4f (&ag)[5],
+                                          const int wave, const int lane, const v4f (&in)[FW],
+                                          G4 g4_ready, SIDE side) {
 #pragma unroll
   for (int k = 0; k < FW; ++k) {
     const float a = ao[k >> 2][k & 3];
@@ -160,7 +176,10 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
   g4_ready(acc_g4);
 }
 
-template <int PDE, int H>
+// ONE_TILE: the launch has at least as many workgroups as tiles (the 10^4-point headline), so the
+// tile loop is a single pass: no loop-carried coordinate prefetch, which lets the compiler wait for
+// the first coordinates without also draining the image DMA issued behind them.
+template <int PDE, int H, bool ONE_TILE>
 __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
                                                   const float* __restrict__ th,
                                                   const float* __restrict__ img,
@@ -172,7 +191,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
                                                   long long* __restrict__ stamps) {
   constexpr int RS4 = 65;
   constexpr int BUFV = FROWS * RS4;                 // v4f elements per exchange buffer
-  constexpr int NW = ((H - 1) * WIMG + 255) / 256 * 256;   // floats of weight image (whole DMA pieces)
+  constexpr int NW = ((H - 1) * WIMG + 1023) / 1024 * 1024;   // floats of weight image (whole rounds of 4 DMA pieces)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const wl = reinterpret_cast<float*>(lds_raw);
   v4f* const xb = reinterpret_cast<v4f*>(wl + NW);
@@ -187,17 +206,20 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
   // this wave's features: local jj = 0..3 -> 4*wave + jj, jj = 4 -> 16 + wave
   auto feat = [&](int jj) { return jj < 4 ? 4 * wave + jj : 16 + wave; };
 
-  // first tile's coordinates: issued ahead of the weight staging
+  // first tile's coordinates
   int tile = blockIdx.x;
   float x = 0.0f, t = 0.0f;
   if (tile < n_tiles) { x = xs[tile * 64 + lane]; t = ts[tile * 64 + lane]; }
 
-  // ---- weight image -> LDS by asynchronous LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
-  // instruction, no registers), in flight while the first tile's input layer is computed; drained
-  // right before the first hidden layer.  Plus the two "ones" rows.
-  for (int c = wave; c < NW / 256; c += 4)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + c * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(wl + c * 256), 16, 0, 0);
+  // first hidden layer of the first tile: its patterns and biases come straight from the global
+  // image into registers, in the same memory round trip as the coordinates -- the LDS image is only
+  // needed from the second hidden layer on
+  v4f pre_o[5], pre_g[5], pre_b, pre_bg;
+  load_patterns(img, wave, lane, pre_o, pre_g);
+  pre_b = *reinterpret_cast<const v4f*>(img + 2 * FW * FW + 4 * wave);
+  pre_bg = *reinterpret_cast<const v4f*>(img + 2 * FW * FW + 16);
+
+  STAMP(19);
   if (wave == 0) {
     xb[0 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
     xb[2 * BUFV + FW * RS4 + lane] = v4f{1, 0, 0, 0};
@@ -255,7 +277,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t - lbt, -1.0f);
     {  // next tile's coordinates: in flight during this tile
       const int nt = tile + gridDim.x;
-      if (nt < n_tiles) { x = xs[nt * 64 + lane]; t = ts[nt * 64 + lane]; }
+      if (!ONE_TILE && nt < n_tiles) { x = xs[nt * 64 + lane]; t = ts[nt * 64 + lane]; }
     }
     v4f stash[H][FF];                            // AGPR-resident (agpr_put4 / agpr_get4)
 
@@ -267,11 +289,26 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       stash[0][jj] = agpr_put4(s);
       xb[feat(jj) * RS4 + lane] = channels4(s);
     }
-    if (image_pending) {                         // first tile only: this wave's DMA pieces have landed
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      image_pending = false;
+    if (image_pending) {                         // the pre-loaded patterns have arrived (same round trip as x, t)
+#pragma unroll
+      for (int m = 0; m < 5; ++m) { consume4(pre_o[m]); consume4(pre_g[m]); }
+      consume4(pre_b); consume4(pre_bg);
+      STAMP(22);
     }
     lds_barrier();
+    if (image_pending) {
+      // ---- weight image -> LDS by asynchronous LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave
+      // instruction, no registers), in flight during the first hidden layer and drained before the
+      // second.  Written as inline assembly on purpose: hipcc makes every LDS access that follows a
+      // DMA it knows about wait for vmcnt(0) (it cannot tell the image from the exchange tiles),
+      // which would put the whole fetch latency back in front of the first layer.  Unseen, the DMA
+      // can only make the compiler's own vmcnt waits stricter (counters retire in order), and all
+      // its earlier loads have been consumed by now.
+#pragma unroll
+      for (int m = 0; m < NW / 1024; ++m)
+        lds_dma_b128(img + (4 * m + wave) * 256 + lane * 4, wl + (4 * m + wave) * 256);
+      STAMP(23);
+    }
 #pragma unroll
     for (int d = 1; d < H; ++d) {
       const v4f* __restrict__ Xin = xb + ((d - 1) & 1) * BUFV;
@@ -281,19 +318,28 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
 #pragma unroll
       for (int k = 0; k < FW; ++k) xin[k] = Xin[k * RS4 + lane];
       acc4 acc_own[4], acc_g4;
-      acc_own[0] = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 4 * wave);     // bias b_d[4w..4w+3]
+      v4f ao[5], ag[5];
+      if (d == 1 && image_pending) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { ao[m] = pre_o[m]; ag[m] = pre_g[m]; }
+        acc_own[0] = pre_b; acc_g4 = pre_bg;
+      } else {
+        load_patterns(wimg, wave, lane, ao, ag);
+        acc_own[0] = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 4 * wave);   // bias b_d[4w..4w+3]
+        acc_g4 = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 16);
+      }
       acc_own[1] = acc_own[2] = acc_own[3] = acc4{0, 0, 0, 0};
-      acc_g4 = *reinterpret_cast<const v4f*>(wimg + 2 * FW * FW + 16);
       if (wave != 0) acc_g4 = acc4{0, 0, 0, 0};                                      // bias rides on channel h
       if (d == 4) STAMP(24);
       // group 4: this wave's channel of features 16..19 is published as soon as it is complete
-      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, xin,
+      gemv_mfma(acc_own, acc_g4, ao, ag, wave, lane, xin,
                 [&](const acc4& g) {
 #pragma unroll
                   for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = g[i];
                 },
                 [](int) {});
       if (d == 4) STAMP(25);
+      if (d == 1 && image_pending) STAMP(20);
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const v4f s{tanh_r5(acc_own[0][jj]), acc_own[1][jj], acc_own[2][jj], acc_own[3][jj]};
@@ -308,6 +354,11 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
         const v4f s{tanh_r5(z4.x), z4.y, z4.z, z4.w};
         stash[d][4] = agpr_put4(s);
         Xout[(16 + wave) * RS4 + lane] = channels4(s);
+      }
+      if (d == 1 && image_pending) {             // first tile only: this wave's DMA pieces have landed
+        STAMP(21);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        image_pending = false;
       }
       lds_barrier();
       STAMP(1 + d);
@@ -404,7 +455,9 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
           if (c == 3 && p + 2 < 16) { fa4[p & 1] = IN[farow + p + 2]; fb4[p & 1] = ZB[fbrow + p + 2]; }
         }
       };
-      gemv_mfma(acc_own, acc_g4, wimg, wave, lane, zin,
+      v4f ao[5], ag[5];
+      load_patterns(wimg, wave, lane, ao, ag);
+      gemv_mfma(acc_own, acc_g4, ao, ag, wave, lane, zin,
                 [&](const acc4& g) {
 #pragma unroll
                   for (int i = 0; i < 4; ++i) Qf[i * RS4 * 4 + qw] = g[i];
@@ -428,6 +481,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       }
     }
     lds_barrier();          // the next tile's first layer overwrites an exchange buffer
+    if (ONE_TILE) break;
   }
   STAMP(2 * H + 1);
 
@@ -516,16 +570,21 @@ inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th
   const size_t lds = fused20m_lds_bytes(H);
   static unsigned long long attr_set = 0;
   if (first_call_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_fused20m<PDE, H>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused20m<PDE, H, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)k_fused20m<PDE, H, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  const int n_tiles = sd.n_pad / 64;
+  auto* const kern = n_wg >= n_tiles ? k_fused20m<PDE, H, true> : k_fused20m<PDE, H, false>;
   if (ev_start && ev_stop)      // the events take the kernel's own begin / end timestamps (what a profiler reports)
-    hipExtLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd,
-                          th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
+    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd,
+                          th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, stamps);
   else
-    hipLaunchKernelGGL((k_fused20m<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
-                       ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, stamps);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
+                       ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, stamps);
   return (int)hipGetLastError();
 }
 

@@ -63,6 +63,9 @@ def main():
         print("# layer 4 detail (slowest wave per workgroup, median): ")
         print("#  fwd: reads issued..gemv start %.0f | gemv %.0f | Q write + own nonlinear %.0f | barrier wait %.0f | g4 tail+barrier %.0f" % (
             seg(1 + 3, 24), seg(24, 25), seg(25, 26), seg(26, 27), seg(27, 1 + 4)))
+        print("#  prologue: entry..DMA issued %.0f | ..setup done %.0f | dense 0 %.0f | barrier %.0f | layer 1 reads+gemv %.0f | "
+              "nonlinear+exchange %.0f | image wait + barrier %.0f" % (
+                  seg(0, 19), seg(19, 1), seg(1, 22), seg(22, 23), seg(23, 20), seg(20, 21), seg(21, 2)))
         print("#  epilogue: wave sums + first/last layer rows %.0f | dW scatter %.0f" % (seg(2 * H_ + 1, 31), seg(31, 2 * H_ + 2)))
         print("#  bwd: phase A %.0f | barrier wait %.0f | phase B (gemv + dW) %.0f | Q exchange %.0f" % (
             seg(2 * H_ + 1 - 5, 28), seg(28, 29), seg(29, 30), seg(30, 2 * H_ + 1 - 4)))
