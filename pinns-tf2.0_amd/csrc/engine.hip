@@ -115,6 +115,12 @@ struct pinn_ctx {
   double *lb_x = nullptr, *lb_d = nullptr, *lb_gold = nullptr, *lb_S = nullptr, *lb_Y = nullptr,
          *lb_ro = nullptr, *lb_al = nullptr, *lb_q = nullptr, *lb_log_loss = nullptr;
   int* lb_log_iter = nullptr;
+  // pinned host mirrors read back by pinn_lbfgs_run: state + the log entries the call may have produced, three
+  // asynchronous copies behind ONE stream synchronisation (two blocking hipMemcpy more cost ~25 us per call)
+  LbfgsState* h_lb_state = nullptr;
+  double* h_lb_log_loss = nullptr;
+  int* h_lb_log_iter = nullptr;
+  int h_lb_cap_log = 0;
   int lb_max_iter = 0, lb_ncorr = 0, lb_cap_corr = 0, lb_cap_log = 0, lb_logged_read = 0;
   double lb_lr = 1.0, lb_tol_fun = 0, lb_tol_x = 0, lb_max_eval = 0;
   int lb_iters_issued = 0;
@@ -959,6 +965,9 @@ int pinn_destroy(pinn_ctx* c) {
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
+  if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
+  if (c->h_lb_log_iter) (void)hipHostFree(c->h_lb_log_iter);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1202,8 +1211,19 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
                      max_iter, c->lb_max_eval, tol_fun, tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_d,
                      c->lb_log_iter, c->lb_log_loss, 1);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (int rc2 = xg_check(c)) return rc2;
+  if (c->xg.on) {                                 // a lost mailbox peer in the first evaluation surfaces here
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int rc2 = xg_check(c)) return rc2;
+  }                                               // otherwise nothing is read back: pinn_lbfgs_run synchronises
+  if (!c->h_lb_state) HIPCHK(hipHostMalloc((void**)&c->h_lb_state, sizeof(LbfgsState), hipHostMallocDefault));
+  if (max_iter + 1 > c->h_lb_cap_log) {
+    if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
+    if (c->h_lb_log_iter) (void)hipHostFree(c->h_lb_log_iter);
+    c->h_lb_log_loss = nullptr; c->h_lb_log_iter = nullptr; c->h_lb_cap_log = 0;
+    HIPCHK(hipHostMalloc((void**)&c->h_lb_log_loss, (size_t)(max_iter + 1) * 8, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->h_lb_log_iter, (size_t)(max_iter + 1) * 4, hipHostMallocDefault));
+    c->h_lb_cap_log = max_iter + 1;
+  }
   c->lb_ready = true;
   return 0;
 }
@@ -1258,14 +1278,29 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     c->lb_post_pending = false;
   }
   HIPCHK(hipGetLastError());
-  LbfgsState hs;
-  HIPCHK(hipMemcpyAsync(&hs, c->lb_state + c->lb_flip, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+  // state + every log entry this call can have added (one per evaluation settled: at most n_iters + 1), one sync
+  int maybe = c->lb_cap_log - c->lb_logged_read;
+  if (maybe > n_iters + 1) maybe = n_iters + 1;
+  if (!(iters && losses) || maybe < 0) maybe = 0;
+  HIPCHK(hipMemcpyAsync(c->h_lb_state, c->lb_state + c->lb_flip, sizeof(LbfgsState), hipMemcpyDeviceToHost, c->stream));
+  if (maybe > 0) {
+    HIPCHK(hipMemcpyAsync(c->h_lb_log_iter, c->lb_log_iter + c->lb_logged_read, (size_t)maybe * 4,
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_lb_log_loss, c->lb_log_loss + c->lb_logged_read, (size_t)maybe * 8,
+                          hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   if (int rc2 = xg_check(c)) return rc2;
+  const LbfgsState hs = *c->h_lb_state;
   const int fresh = hs.n_logged - c->lb_logged_read;
   if (fresh > 0 && iters && losses) {
-    HIPCHK(hipMemcpy(iters, c->lb_log_iter + c->lb_logged_read, (size_t)fresh * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(losses, c->lb_log_loss + c->lb_logged_read, (size_t)fresh * 8, hipMemcpyDeviceToHost));
+    if (fresh <= maybe) {
+      memcpy(iters, c->h_lb_log_iter, (size_t)fresh * 4);
+      memcpy(losses, c->h_lb_log_loss, (size_t)fresh * 8);
+    } else {                                      // (cannot happen: kept as the general path)
+      HIPCHK(hipMemcpy(iters, c->lb_log_iter + c->lb_logged_read, (size_t)fresh * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(losses, c->lb_log_loss + c->lb_logged_read, (size_t)fresh * 8, hipMemcpyDeviceToHost));
+    }
   }
   c->lb_logged_read = hs.n_logged;
   if (n_logged) *n_logged = fresh > 0 ? fresh : 0;

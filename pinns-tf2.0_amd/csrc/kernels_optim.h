@@ -436,7 +436,7 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 
 #ifdef PINN_STAMPS
 __device__ long long g_coef_stamps[16];         // s_memtime timeline of the last k_lbc_coef (profiling build)
-#define CSTAMP(i) do { if (threadIdx.x == 0) g_coef_stamps[i] = clock64(); } while (0)
+#define CSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_coef_stamps[i] = clock64(); } while (0)
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
