@@ -117,7 +117,9 @@ int pinn_adam_run_terms(pinn_ctx* c, int n_steps, double* terms3);
  * evaluation (:65-76); pinn_lbfgs_run advances up to n_iters iterations.
  *   iters[i], losses[i]: the (nIter, f) pairs custom_lbfgs would have passed to log_fn (:217-218)
  *   n_logged: how many pairs were written;  done: 0 running, 1 maxIter reached, >1 break reason
- * The last-iteration quirk is reproduced: the model weights end at the last *evaluated* x. */
+ * The last-iteration quirk is reproduced: the model weights end at the last *evaluated* x.
+ * pinn_lbfgs_begin only enqueues (it returns before the initial evaluation has run, except with the
+ * mailbox exchange attached); pinn_lbfgs_run synchronises once, at its end, to read state and log. */
 int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double tol_fun,
                      double tol_x, double max_eval);
 int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged,
