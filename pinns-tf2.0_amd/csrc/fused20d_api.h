@@ -14,7 +14,7 @@ constexpr int fused20d_blocks(int H) { return 5 + (H - 1) * 30 + 6; }
 // the flat weight vector is brought into LDS by LDS-DMA in whole 1-KiB pieces (128 doubles)
 inline size_t fused20d_weight_doubles(int n_theta) { return ((size_t)n_theta + 127) / 128 * 128; }
 inline size_t fused20d_lds_bytes(int n_hidden, int n_theta) {
-  return (fused20d_weight_doubles(n_theta) + (size_t)4 * fused20d_blocks(n_hidden) * 16) * sizeof(double);
+  return (fused20d_weight_doubles(n_theta) + (size_t)4 * fused20d_blocks(n_hidden) * 16 + 4 * 256) * sizeof(double);   // + loss-part slots
 }
 
 // entry e = 16 * block + 4 * i + j of a wave's block list -> flat parameter index (reference layout), -1 = padding

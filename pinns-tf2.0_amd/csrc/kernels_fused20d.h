@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
   {
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2* const z = reinterpret_cast<d2*>(gacc_all);
-    for (int i = tid; i < 2 * NBLK * 16; i += 256) z[i] = d2{0.0, 0.0};
+    for (int i = tid; i < 2 * NBLK * 16 + 2 * 256; i += 256) z[i] = d2{0.0, 0.0};   // + the loss-part slots behind them
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
   double c1 = 1.0, c2 = nu;
   if (PDE == 1) { c1 = wl[nd.n_net]; c2 = exp(wl[nd.n_net + 1]); }
   const double inv_nf = sd.inv_nf, inv_nu = sd.inv_nu;
-  double l_res = 0.0, l_dat = 0.0, dl0 = 0.0, dl1 = 0.0;       // per-lane partial sums (slot-0 lanes only)
+  // per-lane partial sums of the loss parts and of the two lambda gradients (slot-0 lanes only) live in LDS, four
+  // slots per lane behind the gradient accumulators: one read-modify-write per tile instead of eight registers held
+  // across the whole kernel (which cost the identification variant 20 B of scratch per lane)
+  double* const lacc = gacc_all + 4 * NBLK * 16 + wave * 256 + lane;       // [k * 64]: l_res, l_dat, dl0, dl1
   const double onesA = i4 == 0 ? 1.0 : 0.0;                     // rotated "ones" in-group: row 0 = 1 (bias gradients)
 
   // Gradient blocks.  D = this lane's partial sum over the four points of its block b; the four blocks of an entry
@@ -258,14 +261,14 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
         const double f = o[2] + c1 * o[0] * o[1] - c2 * o[3];
         const double fbar = 2.0 * f * wgt;
         if (s == 0) {
-          l_res += f * f * wgt;
-          if (PDE == 1) { dl0 += fbar * o[0] * o[1]; dl1 -= fbar * c2 * o[3]; }
+          lacc[0] += f * f * wgt;
+          if (PDE == 1) { lacc[128] += fbar * o[0] * o[1]; lacc[192] -= fbar * c2 * o[3]; }
         }
         sb[0] = fbar * c1 * o[1]; sb[1] = fbar * c1 * o[0]; sb[2] = fbar; sb[3] = -c2 * fbar;
       }
       if (cls == CLS_DATA) {
         const double dd = o[0] - tgt[pt];
-        if (s == 0) l_dat += dd * dd * inv_nu;
+        if (s == 0) lacc[64] += dd * dd * inv_nu;
         sb[0] += 2.0 * dd * inv_nu;
       }
     }
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
       const int e = tid + 256 * it;
       idx[it] = e < NE ? row_index[e] : -1;
     }
-    const double t0 = wave_sum(l_res), t1 = wave_sum(l_dat);
-    const double t2 = PDE == 1 ? wave_sum(dl0) : 0.0, t3 = PDE == 1 ? wave_sum(dl1) : 0.0;
+    const double t0 = wave_sum(lacc[0]), t1 = wave_sum(lacc[64]);
+    const double t2 = PDE == 1 ? wave_sum(lacc[128]) : 0.0, t3 = PDE == 1 ? wave_sum(lacc[192]) : 0.0;
     __syncthreads();                                   // every wave's accumulators are final
     double* const scal = wl;                           // the weight copy is dead: 4 x 4 loss / lambda partials
     if (lane == 0) { scal[wave * 4 + 0] = t0; scal[wave * 4 + 1] = t1; scal[wave * 4 + 2] = t2; scal[wave * 4 + 3] = t3; }
