@@ -73,10 +73,12 @@ def test_burgers_eval_vs_golden_and_oracle(burgers_sets, dtype, path, tag, N_u, 
     eng.close()
 
 
-@pytest.mark.parametrize("N_f", [40000, 100001])
+@pytest.mark.parametrize("N_f", [16284, 16300, 40000, 100001])
 def test_burgers_persistent_tiles_f32(burgers_sets, N_f):
     """more 64-point tiles than compute units: the register-stash kernel (path 2) loops over tiles
-    inside a workgroup and must agree with the oracle and with the generic kernels (path 0)"""
+    inside a workgroup and must agree with the oracle and with the generic kernels (path 0).
+    16284 + 100 points = 256 tiles = one per compute unit (the last launch the one-tile specialisation
+    serves), 16300 -> 257 tiles (the first one the tile loop serves)"""
     from oracle import pde
     g = np.load(golden("burgers_eval.npz"))
     eng, layers, (lb, ub, X_f, X_u, u) = make_burgers(burgers_sets, 100, N_f, "f32", 2)
