@@ -41,6 +41,15 @@
 
 namespace pinn {
 
+// Ablation builds (profiles/ablate_fused20m.py, -DPINN_ABL=n): one ingredient of k_fused20m compiled out at a time --
+// the results are WRONG by construction, only the step time is read.  0 / undefined = the product kernel.
+//   1 no dW matrix instructions     2 no group-4 chain, exchange and its barrier     3 workgroup barriers -> LDS waits only
+//   4 tanh -> one multiply          5 no AGPR stash traffic                          6 no adjoint / channel arithmetic in phase A
+//   7 no own-group GEMV matrix instructions
+#ifndef PINN_ABL
+#define PINN_ABL 0
+#endif
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -48,14 +57,22 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // there explicitly (instead of letting the allocator spill to AGPRs) keeps it out of the VGPR
 // pressure the scheduler reasons about, so LDS reads can be hoisted well ahead of their use.
 __device__ __forceinline__ float agpr_put(const float x) {
+#if PINN_ABL == 5
+  return 0.25f;
+#else
   float a;
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(x));
   return a;
+#endif
 }
 __device__ __forceinline__ float agpr_get(const float a) {
+#if PINN_ABL == 5
+  return a;
+#else
   float x;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
   return x;
+#endif
 }
 __device__ __forceinline__ v4f agpr_put4(const v4f s) {
   return v4f{agpr_put(s.x), agpr_put(s.y), agpr_put(s.z), agpr_put(s.w)};
@@ -74,6 +91,9 @@ __device__ __forceinline__ void consume4(v4f& v) { asm volatile("" : "+v"(v)); }
 
 // tanh(x) = 1 - 2 / (1 + e^{2x}); absolute error ~1 ulp of 1.0 (cf. tanh_bf)
 __device__ __forceinline__ float tanh_r5(float x) {
+#if PINN_ABL == 4
+  return x * 0.125f;
+#endif
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
 }
@@ -87,6 +107,9 @@ __device__ __forceinline__ v4f channels4(const v4f s) {
 
 // adjoint of the pre-activation channels (A.3)
 __device__ __forceinline__ v4f preact_adjoint4(const v4f s, const v4f ob) {
+#if PINN_ABL == 6
+  return ob;
+#endif
   const float a = s.x, a2 = a * a, d1 = 1.0f - a2;
   const float d2 = (-2.0f * a) * d1;
   const float d3 = (-2.0f * d1) * fmaf(-3.0f, a2, 1.0f);
@@ -152,6 +175,10 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
 #pragma unroll
   for (int k = 0; k < FW; ++k) {
     const float a = ao[k >> 2][k & 3];
+#if PINN_ABL == 7
+    acc_own[0].x += a * in[k].x; acc_own[1].x += a * in[k].y; acc_own[2].x += a * in[k].z; acc_own[3].x += a * in[k].w;
+    side(4 * k); side(4 * k + 1); side(4 * k + 2); side(4 * k + 3);
+#else
     acc_own[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].x, acc_own[0], 0, 0, 0);
     side(4 * k);
     acc_own[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].y, acc_own[1], 0, 0, 0);
@@ -160,7 +187,13 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
     side(4 * k + 2);
     acc_own[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, in[k].w, acc_own[3], 0, 0, 0);
     side(4 * k + 3);
+#endif
   }
+#if PINN_ABL == 2
+  acc_g4.x += ag[0].x * in[0].x;
+  g4_ready(acc_g4);
+  return;
+#endif
   // group 4, one channel per wave: uniform branch, only the selected 20 MFMAs execute; two
   // accumulators so that consecutive MFMAs do not depend on each other.  (Running this unit
   // first, to cover its LDS exchange with the own-group MFMAs, measured 5 % slower per layer.)
@@ -347,10 +380,16 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
         Xout[(4 * wave + jj) * RS4 + lane] = channels4(s);
       }
       if (d == 4) STAMP(26);
+#if PINN_ABL != 2
       lds_barrier();
+#endif
       if (d == 4) STAMP(27);
       {
+#if PINN_ABL == 2
+        const v4f z4 = v4f{acc_own[0][0], acc_own[1][0], acc_own[2][0], acc_own[3][0]};
+#else
         const v4f z4 = Q[wave * RS4 + lane];      // feature 16+wave: (h, p, q, r) pre-activations
+#endif
         const v4f s{tanh_r5(z4.x), z4.y, z4.z, z4.w};
         stash[d][4] = agpr_put4(s);
         Xout[(16 + wave) * RS4 + lane] = channels4(s);
@@ -443,6 +482,9 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       for (int c = 0; c < 4; ++c) acc_own[c] = acc4{0, 0, 0, 0};
       acc4 accm = dwm[d], accf = dwf[d];
       auto dw_mfma = [&](int s) {              // s = 0..79, one after every own-group GEMV MFMA
+#if PINN_ABL == 1
+        return;
+#endif
         if (s % 5 == 4) {                      // 16 main-block MFMAs: step jj = m/4, channel m%4
           const int m = s / 5, jj = m >> 2, c = m & 3;
           const v4f a = ma[jj & 1], b = mb[jj & 1];
@@ -467,8 +509,12 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       if (d == 4) STAMP(30);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) ob[kk] = v4f{acc_own[0][kk], acc_own[1][kk], acc_own[2][kk], acc_own[3][kk]};
+#if PINN_ABL == 2
+      ob[4] = ob[0];
+#else
       lds_barrier();
       ob[4] = Q[wave * RS4 + lane];
+#endif
       STAMP(2 * H + 1 - d);
     }
     {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
