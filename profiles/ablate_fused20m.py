@@ -1,16 +1,39 @@
 """Ablation of k_fused20m: Adam step time of the headline workload with one ingredient compiled out at a time
 (-DPINN_ABL=n, see csrc/kernels_fused20m.h; the results of those builds are wrong by construction, only the time is read).
 
-    # build (CPU): one shared object per variant
-    for n in 0..7: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -DPINN_ABL=n -c csrc/engine.hip ...
-    # run (GPU):
-    python profiles/ablate_fused20m.py DIR_WITH_libpinn_hip_abl{n}.so"""
+    python profiles/ablate_fused20m.py --build [DIR]     # CPU: one libpinn_hip_abl{n}.so per variant (default DIR: pinn_native/abl, git-ignored)
+    python profiles/ablate_fused20m.py [DIR]             # GPU: times them"""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "pinns-tf2.0_amd", "pinn_native", "abl")
+PKG = os.path.join(ROOT, "pinns-tf2.0_amd")
+
+
+def build(d):
+    """one shared object per variant (hipcc cross-compiles without a GPU; ~2 minutes, eight compiles in parallel);
+    the float64 unit is taken from the product build"""
+    os.makedirs(d, exist_ok=True)
+    hipcc = "/opt/rocm/bin/hipcc"
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+    procs = [(n, subprocess.Popen(common + ["-DPINN_ABL=%d" % n, "-c", os.path.join(PKG, "csrc", "engine.hip"), "-o",
+                                            os.path.join(d, "engine_abl%d.o" % n)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for n in range(8)]
+    for n, p in procs:
+        out = p.communicate()[0]
+        if p.returncode:
+            raise SystemExit("variant %d failed:\n%s" % (n, out[-3000:]))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(d, "engine_abl%d.o" % n),
+                               os.path.join(PKG, "pinn_native", "fused20d_unit.o"), "-o",
+                               os.path.join(d, "libpinn_hip_abl%d.so" % n), "-lrccl"])
+        os.remove(os.path.join(d, "engine_abl%d.o" % n))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--build":
+    build(sys.argv[2] if len(sys.argv) > 2 else os.path.join(PKG, "pinn_native", "abl"))
+    raise SystemExit(0)
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(PKG, "pinn_native", "abl")
 NAMES = {0: "product kernel", 1: "no dW matrix instructions", 2: "no group-4 chain / exchange / its barrier",
          3: "workgroup barriers -> LDS waits only", 4: "tanh -> one multiply", 5: "no AGPR stash traffic",
          6: "no adjoint arithmetic in phase A", 7: "no own-group GEMV matrix instructions"}
