@@ -41,9 +41,20 @@
 
 namespace pinn {
 
+// Ablation builds (profiles/ablate_fused20d.py, -DPINN_ABLD=n): one ingredient of k_fused20d compiled out at a time --
+// wrong results by construction, only the step time is read.  0 / undefined = the product kernel.
+//   1 gradient blocks: no DPP fold, no LDS accumulate     2 no gradient-block matrix instructions either
+//   3 tanh -> one multiply     4 lane rotations (2 x ds_bpermute) -> identity     5 no AGPR stash traffic
+#ifndef PINN_ABLD
+#define PINN_ABLD 0
+#endif
+
 // a double parked in the accumulation half of the register file (two 32-bit AGPRs)
 struct agd { int lo, hi; };
 __device__ __forceinline__ agd agd_put(const double x) {
+#if PINN_ABLD == 5
+  return agd{1, 2};
+#endif
   agd a;
   const int lo = __double2loint(x), hi = __double2hiint(x);
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(lo));
@@ -56,6 +67,9 @@ __device__ __forceinline__ agd agd_put(const double x) {
 // VALU instruction that reads x: the extra operand orders the asm behind that instruction, whose own hazard wait
 // the compiler did insert.
 __device__ __forceinline__ agd agd_put_after(const double x, const double after) {
+#if PINN_ABLD == 5
+  return agd{1, 2};
+#endif
   agd a;
   const int lo = __double2loint(x), hi = __double2hiint(x), dep = __double2hiint(after);
   asm("v_accvgpr_write_b32 %0, %1" : "=a"(a.lo) : "v"(lo), "v"(dep));
@@ -63,6 +77,9 @@ __device__ __forceinline__ agd agd_put_after(const double x, const double after)
   return a;
 }
 __device__ __forceinline__ double agd_get(const agd a) {
+#if PINN_ABLD == 5
+  return __hiloint2double(a.hi, a.lo);
+#endif
   int lo, hi;
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(lo) : "a"(a.lo));
   asm("v_accvgpr_read_b32 %0, %1" : "=v"(hi) : "a"(a.hi));
@@ -75,6 +92,9 @@ __device__ __forceinline__ double mfma444(const double a, const double b, const 
 
 // value of lane (src4 >> 2) -- any permutation of the wave, 2 x ds_bpermute_b32
 __device__ __forceinline__ double lane_fetch(const double x, const int src4) {
+#if PINN_ABLD == 4
+  return x;
+#endif
   const int lo = __builtin_amdgcn_ds_bpermute(src4, __double2loint(x));
   const int hi = __builtin_amdgcn_ds_bpermute(src4, __double2hiint(x));
   return __hiloint2double(hi, lo);
@@ -86,6 +106,9 @@ constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 // the scaling / fix-up of an IEEE division: v_rcp_f64 seed + two Newton steps (relative error < 1e-30 before the
 // final rounding), 5 instructions instead of 11.
 __device__ __forceinline__ double tanh_d(const double x) {
+#if PINN_ABLD == 3
+  return x * 0.125;
+#endif
   const double t = exp(-2.0 * fabs(x));
   const double y = 1.0 + t;
   double r = __builtin_amdgcn_rcp(y);
@@ -120,7 +143,9 @@ __device__ __forceinline__ void preact_adjoint_d(const double a, const double zp
   br = d1 * orr;
 }
 
-template <int PDE, int H>
+// ONE_TILE: the launch has at least as many workgroups as tiles: every gradient block is produced exactly once, so
+// it is stored, not accumulated (no LDS read-modify-write), and there is no loop-carried coordinate prefetch.
+template <int PDE, int H, bool ONE_TILE>
 __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const double* __restrict__ th,
                                                   const double* __restrict__ xs, const double* __restrict__ ts,
                                                   const double* __restrict__ tgt, double lbx, double lbt, double sx,
@@ -178,12 +203,22 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
   // are folded with two DPP row rotations -- commutative, so the four lanes of an entry end with bit-identical
   // totals and may all store (same value, same address: no exec masking, no branch).  The old accumulator values
   // are fetched BEFORE the matrix instructions that produce D (grad_fetch), so no LDS round trip is exposed.
-  auto grad_fetch = [&](const int blk) { return gacc[blk * 16 + ge]; };
+#if PINN_ABLD == 1 || PINN_ABLD == 2
+  double abl_sink = 0.0;
+  auto grad_fetch = [&](const int) { return 0.0; };
+  auto grad_store = [&](double D, const double, const int) {
+#if PINN_ABLD == 1
+    abl_sink += D;                               // keeps the matrix instructions, drops fold and accumulate
+#endif
+  };
+#else
+  auto grad_fetch = [&](const int blk) { return ONE_TILE ? 0.0 : gacc[blk * 16 + ge]; };
   auto grad_store = [&](double D, const double old, const int blk) {
     D += dpp_mov<DPP_ROW_ROR8>(D);
     D += dpp_mov<DPP_ROW_ROR4>(D);
-    gacc[blk * 16 + ge] = old + D;
+    gacc[blk * 16 + ge] = ONE_TILE ? D : old + D;
   };
+#endif
   // (Tried: ds_add_f64 with the four lanes of an entry hitting one address, no fold, no read-modify-write --
   //  221 instructions instead of ~3000, bit-reproducible over 200 runs, and 14 % SLOWER: 49.8 vs 43.7 us per step.)
 
@@ -194,7 +229,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
     const double hx = __builtin_fma(sx, x - lbx, -1.0), ht = __builtin_fma(st, t - lbt, -1.0);
     {
       const int nt = tile + gridDim.x;
-      if (nt < n_tiles) { x = xs[nt * 64 + wave * 16 + q]; t = ts[nt * 64 + wave * 16 + q]; }
+      if (!ONE_TILE && nt < n_tiles) { x = xs[nt * 64 + wave * 16 + q]; t = ts[nt * 64 + wave * 16 + q]; }
     }
 
     // ------------------------------------------------------------------ forward
@@ -402,6 +437,7 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
 #pragma unroll
       for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], n);
     }
+    if (ONE_TILE) break;
   }
   STAMP(2 * H + 1);
 
@@ -416,6 +452,9 @@ __global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const 
       const int e = tid + 256 * it;
       idx[it] = e < NE ? row_index[e] : -1;
     }
+#if PINN_ABLD == 1
+    lacc[0] += abl_sink;
+#endif
     const double t0 = wave_sum(lacc[0]), t1 = wave_sum(lacc[64]);
     const double t2 = PDE == 1 ? wave_sum(lacc[128]) : 0.0, t3 = PDE == 1 ? wave_sum(lacc[192]) : 0.0;
     __syncthreads();                                   // every wave's accumulators are final
@@ -453,16 +492,20 @@ inline int fused20d_launch(const NetDesc& nd, const SetDesc& sd, const double* t
   const size_t lds = fused20d_lds_bytes(H, nd.n_theta);
   static unsigned long long attr_set = 0;
   if (first_call_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_fused20d<PDE, H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)k_fused20d<PDE, H, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)k_fused20d<PDE, H, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
+  const int n_tiles = sd.n_pad / 64;
+  auto* const kern = n_wg >= n_tiles ? k_fused20d<PDE, H, true> : k_fused20d<PDE, H, false>;
   if (ev_start && ev_stop)
-    hipExtLaunchKernelGGL((k_fused20d<PDE, H>), dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd, th,
-                          xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, sd.n_pad / 64, row_index, stamps);
+    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd, th,
+                          xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, row_index, stamps);
   else
-    hipLaunchKernelGGL((k_fused20d<PDE, H>), dim3(n_wg), dim3(256), lds, stream, nd, sd, th, xs, ts, tgt, lbx, lbt,
-                       sx, st, nu, part, R, sd.n_pad / 64, row_index, stamps);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, nd, sd, th, xs, ts, tgt, lbx, lbt,
+                       sx, st, nu, part, R, n_tiles, row_index, stamps);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,51 @@
+"""Ablation of k_fused20d (float64): Adam step time of the headline workload with one ingredient compiled out at a time
+(-DPINN_ABLD=n, see csrc/kernels_fused20d.h; the results of those builds are wrong by construction, only the time is read).
+
+    python profiles/ablate_fused20d.py --build [DIR]     # CPU: one libpinn_hip_abld{n}.so per variant (default DIR: pinn_native/abl)
+    python profiles/ablate_fused20d.py [DIR]             # GPU: times them"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pinns-tf2.0_amd")
+NAMES = {0: "product kernel", 1: "gradient blocks: no DPP fold, no LDS accumulate", 2: "no gradient-block matrix instructions either",
+         3: "tanh -> one multiply", 4: "lane rotations (2 x ds_bpermute) -> identity", 5: "no AGPR stash traffic"}
+
+
+def build(d):
+    os.makedirs(d, exist_ok=True)
+    hipcc = "/opt/rocm/bin/hipcc"
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-mllvm",
+              "-amdgpu-mfma-vgpr-form=1"]
+    procs = [(n, subprocess.Popen(common + ["-DPINN_ABLD=%d" % n, "-c", os.path.join(PKG, "csrc", "fused20d_unit.hip"),
+                                            "-o", os.path.join(d, "f20d_abl%d.o" % n)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for n in NAMES]
+    for n, p in procs:
+        out = p.communicate()[0]
+        if p.returncode:
+            raise SystemExit("variant %d failed:\n%s" % (n, out[-3000:]))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(PKG, "pinn_native", "engine.o"),
+                               os.path.join(d, "f20d_abl%d.o" % n), "-o", os.path.join(d, "libpinn_hip_abld%d.so" % n),
+                               "-lrccl"])
+        os.remove(os.path.join(d, "f20d_abl%d.o" % n))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--build":
+    build(sys.argv[2] if len(sys.argv) > 2 else os.path.join(PKG, "pinn_native", "abl"))
+    raise SystemExit(0)
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(PKG, "pinn_native", "abl")
+base = None
+for n in NAMES:
+    lib = os.path.join(d, "libpinn_hip_abld%d.so" % n)
+    if not os.path.exists(lib):
+        continue
+    env = dict(os.environ, PINN_HIP_LIB=lib)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "step_time.py"), "f64", "300"], env=env,
+                         capture_output=True, text=True).stdout
+    us = [float(l.split(":")[2].split("us/step")[0]) for l in out.splitlines() if "us/step" in l]
+    if not us:
+        print("%d %-52s failed" % (n, NAMES[n])); continue
+    t = min(us[1:]) if len(us) > 1 else us[0]
+    base = t if n == 0 else base
+    print("%d %-52s %6.2f us per Adam step  (%+.2f us)" % (n, NAMES[n], t, t - (base or t)), flush=True)
