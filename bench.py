@@ -12,12 +12,15 @@ default epochs, 1d-burgers/inf_cont_burgers.py:35-41), canonical glorot init, in
 
 Timing: W untimed warm-up steps; then blocks of EXACTLY K steps, each bracketed by barrier + stream sync on both sides
 (barrier + sync before, sync + MAX-over-ranks reduction after) ; blocks are repeated (same initial state each time, reset outside the bracket) until
->= 50 ms have been timed, and the MEDIAN block is reported -- a single 20-step block is 1 ms, below the noise of a
-fresh box.  `value` = N_f_total x K / median block.  The kernel duration behind `roofline` is measured live in a
+>= 3 s have been timed per leg (PINN_BENCH_MIN_TIMED_MS), and the MEDIAN block is reported -- a single 20-step block
+is 1 ms, below the noise of a fresh box, and 50 ms per leg (rounds 1-2) was too short for the driver's 5-second
+GPU-busy sampler to corroborate.  `value` = N_f_total x K / median block.  The kernel duration behind `roofline` is measured live in a
 separate pass of the same steps with HIP events attached to the launches themselves (>= 32 samples).
 
-One JSON line on rank 0.  Beside the headline (float32 kernels, the FP32 mode north_star sanctions) it carries
-  float64_leg   the same K steps in the reference's own arithmetic, with its own roofline
+One JSON line on rank 0.  The headline is float64 -- the reference's arithmetic (utils/neuralnetwork.py:24-26) and
+the product's default (hp["dtype"]); --dtype f32 swaps the roles.  Beside it the line carries
+  float32_leg   the same K steps on the float32 kernels (the FP32 mode north_star sanctions), with its own roofline
+                (float64_leg under --dtype f32)
   cfg5_leg      BASELINE configs[4]: N_f = 10^6 in total, sharded over the N ranks (125k per GPU at N = 8); at N = 1
                 this is the steady-state (many tiles per CU) figure of the same kernel
   final_l2_error{,_f64}   the reference's default schedule end to end in both arithmetics, beside the reference's own
@@ -51,8 +54,8 @@ M_W = sum(a * b for a, b in zip(LAYERS[:-1], LAYERS[1:]))          # 2860 MACs p
 NU = 0.01 / np.pi
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}                          # MI355X_MICROARCH.md: vector = matrix FP32/FP64 peak
 HBM_PEAK_GBPS = 8000.0
-MIN_TIMED_MS = 50.0
-MAX_BLOCKS = 400
+MIN_TIMED_MS = float(os.environ.get("PINN_BENCH_MIN_TIMED_MS", "3000"))   # per leg: long enough for the driver's
+MAX_BLOCKS = 8000                                                         # 5-second GPU-busy sampler to see the legs
 KERNEL_NAMES = {2: "pinn::k_fused20m", 1: "pinn::k_fused20", 7: "pinn::k_fused20d", 0: "pinn::k_forward+k_backward",
                 3: "pinn::k_wide_fwd+k_wide_bwd"}
 LAUNCH_FLOOR_US = 4.5                                              # a trivial launch on this stream
@@ -235,8 +238,7 @@ def final_error(eng, w0, X_star, u_star):
     d = 0
     while not d:
         _, _, d = eng.lbfgs_run(200)
-    u_pred = eng.predict(X_star)
-    return float(np.linalg.norm(u_star - u_pred, 2) / np.linalg.norm(u_star, 2))
+    return float(eng.error_l2(X_star, u_star))         # device-side reduction (pinn_error_l2)
 
 
 def reference_ensemble():
@@ -336,7 +338,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--dtype", default=os.environ.get("PINN_BENCH_DTYPE", "f32"), choices=["f32", "f64"])
+    ap.add_argument("--dtype", default=os.environ.get("PINN_BENCH_DTYPE", "f64"), choices=["f32", "f64"],
+                    help="arithmetic of the headline leg; f64 = the reference's (utils/neuralnetwork.py:24-26) and the "
+                         "product's default; the other arithmetic is carried as float32_leg / float64_leg")
     ap.add_argument("--nf-total", type=int, default=10000,
                     help="collocation points in total, split over the ranks (strong scaling; the metric's N_f = 10000)")
     ap.add_argument("--nf-per-gpu", type=int, default=0,
@@ -344,7 +348,8 @@ def main():
     ap.add_argument("--kernel-path", type=int, default=-1, help="-1 engine default; see pinn_set_kernel_path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-error", action="store_true")
-    ap.add_argument("--no-f64-leg", action="store_true", help="skip the float64 (reference arithmetic) leg")
+    ap.add_argument("--no-f64-leg", "--no-other-leg", dest="no_f64_leg", action="store_true",
+                    help="skip the leg in the other arithmetic (float32_leg under --dtype f64, float64_leg under f32)")
     ap.add_argument("--no-cfg5-leg", action="store_true", help="skip the N_f = 10^6 leg (BASELINE configs[4])")
     args = ap.parse_args()
 
@@ -405,18 +410,20 @@ def main():
         errs[args.dtype] = final_error(eng, w0, X_star, u_star)
     eng.close()
 
-    # ---- float64 leg: the same steps in the reference's arithmetic ------------------------------------------------
-    f64_leg = None
-    if args.dtype == "f32" and not args.no_f64_leg:
-        f64_leg, e64 = leg("float64", "f64", device, data, w0, wd, k_adam, k_lbfgs, min(args.warmup, 9), spin=False,
-                           init_comm=init_comm)
-        with_traffic(f64_leg, world)
+    # ---- the same steps in the other arithmetic (float32 = the throughput mode north_star sanctions, when the
+    # headline is the reference's float64; float64 when the headline was asked for in float32) -----------------------
+    other = "f32" if args.dtype == "f64" else "f64"
+    other_leg = None
+    if not args.no_f64_leg:
+        other_leg, e2 = leg("float32" if other == "f32" else "float64", other, device, data, w0, wd, k_adam, k_lbfgs,
+                            min(args.warmup, 9), spin=False, init_comm=init_comm)
+        with_traffic(other_leg, world)
         if not args.no_final_error:
             if n_f_total != 10000:
                 from pinn_native.parallel import attach_shards
-                attach_shards(e64, world, rank, X_f=ref_data[0], X_u=ref_data[1], u=ref_data[2])
-            errs["f64"] = final_error(e64, w0, X_star, u_star)
-        e64.close()
+                attach_shards(e2, world, rank, X_f=ref_data[0], X_u=ref_data[1], u=ref_data[2])
+            errs[other] = final_error(e2, w0, X_star, u_star)
+        e2.close()
 
     # ---- cfg 5: N_f = 10^6 in total, sharded over the ranks (BASELINE configs[4]) ---------------------------------
     cfg5 = None
@@ -425,6 +432,10 @@ def main():
         cfg5, e5 = leg("cfg5", args.dtype, device, data5, w0, wd, k_adam, k_lbfgs, min(args.warmup, 6),
                        args.kernel_path, spin=False, init_comm=init_comm)
         with_traffic(cfg5, world)
+        cfg5["note"] = ("BASELINE configs[4]: the throughput regime, and the leg multi-GPU scaling is to be judged on "
+                        "(the N_f = 10000 headline is one tile per workgroup: its step is a latency chain that "
+                        "sharding cannot shorten).  scaling_vs_n1_estimate inputs: ms_per_step here at N ranks vs the "
+                        "N = 1 line, allreduce_probe_us = one [P+4] float64 exchange on this node")
         e5.close()
 
     # every rank empties its C stdio buffer (RCCL's banner) before rank 0 prints: the JSON line stays the last line
@@ -439,13 +450,20 @@ def main():
     if dist is not None:
         dist.barrier()
     if rank == 0:
+        ens = reference_ensemble()
+
+        def delta(v):
+            return abs(v - ens["reference"]) if (v is not None and ens) else None
         out = {
             "metric": "collocation-points/sec",
             "value": main_leg["value"], "unit": "collocation-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_leg["ms_per_step"],
             "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype,
+            "data": "reference fixture 1d-burgers/data/burgers_shock.mat (N_u=100 boundary/initial samples, the "
+                    "25600-point error grid) + Latin-hypercube collocation points, numpy seed 1234 (the reference's "
+                    "prep_data stream); canonical glorot initial weights, seed 1234",
             "config": {"workload": "1D Burgers continuous inference (BASELINE configs[1]): 8x20 tanh MLP, N_u=100, "
                                    "N_f=%d in total over %d GPU(s) (LHS, seed 1234), %d Adam + %d L-BFGS iterations "
                                    "per block, canonical glorot init" % (n_f_total, world, k_adam, k_lbfgs),
@@ -459,10 +477,18 @@ def main():
                        "ms_per_step_min_block": main_leg["ms_per_step_min_block"]},
             "valid": main_leg["valid"],
             "roofline": main_leg["roofline"],
-            "float64_leg": f64_leg,
+            ("float32_leg" if other == "f32" else "float64_leg"): other_leg,
             "cfg5_leg": cfg5,
             "final_l2_error": errs.get(args.dtype), "final_l2_error_f64": errs.get("f64"),
-            "final_l2_error_reference": reference_ensemble(),
+            "final_l2_error_f32": errs.get("f32"),
+            "final_l2_error_reference": ens,
+            # north_star's literal criterion, per arithmetic: |final error - the reference's k = 0 run| (<= 1e-3 asked;
+            # the reference's own runs differ by more than that between two hosts)
+            "final_l2_error_abs_delta": delta(errs.get(args.dtype)), "final_l2_error_abs_delta_f64": delta(errs.get("f64")),
+            "final_l2_error_abs_delta_f32": delta(errs.get("f32")),
+            "final_l2_error_within_1e-3": {k: (delta(v) is not None and delta(v) <= 1e-3) for k, v in errs.items()},
+            "final_l2_error_inside_reference_ensemble": {k: (ens is not None and ens["ensemble_min"] <= v <= ens["ensemble_max"])
+                                                         for k, v in errs.items()},
             "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults, on the "
                                        "reference set N_f=10000 (sharded over the ranks)",
         }

@@ -46,7 +46,8 @@ enum {
 
 /* diagnostics */
 const char* pinn_last_error(void);
-int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6; 3: + pinn_residual_at */
+int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6; 3: + pinn_residual_at;
+                                 4: + pinn_error_l2, pinn_get_status */
 int pinn_device_count(int* n);
 /* name[0..cap) <- hipDeviceProp_t.gcnArchName etc. for Logger's banner (utils/logger.py:13-15) */
 int pinn_device_info(int device, char* name, int cap, int* n_cu, int64_t* hbm_bytes);
@@ -133,12 +134,25 @@ int pinn_lbfgs_get_x(pinn_ctx* c, double* x, int64_t n);
 
 /* self.model(X_star) (utils/neuralnetwork.py:151-153): out[N, n_out] */
 int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out);
+/* The scripts' error metric on the device: err = ||ref - pred||_2 / ||ref||_2 with pred = self.model(X) at the
+ * n points X [n][2] (1d-burgers/inf_cont_burgers.py:114-116 via utils/logger.py:56-60) -- forward sweep, fixed-order
+ * float64 reduction, 24 bytes back.  kind 0: ref is [n][n_out], compared element-wise; kind 1: ref is [n] and is
+ * compared with the modulus sqrt(sum_o pred_o^2) (the |h| of 1dcomplex-schrodinger/inf_cont_schrodinger.py:155-158).
+ * X and ref are kept on the device: a repeated call with the same grid (and pinn_predict / pinn_residual_at on it)
+ * uploads nothing. */
+int pinn_error_l2(pinn_ctx* c, const double* X, const double* ref, int64_t n, int kind, double* err);
 /* f_model() at the stored collocation points (inf_cont_burgers.py:65-90): f[n_f, n_out]
  * (IDE: at the data points) */
 int pinn_residual(pinn_ctx* c, double* f, int64_t n);
 /* f_model(X) at n caller-supplied points X [n][2] -> f [n][n_out]: what the identification script's predict
  * evaluates on X_star (1d-burgers/ide_cont_burgers.py:169-172) */
 int pinn_residual_at(pinn_ctx* c, const double* X, int64_t n, double* f);
+
+/* Failure detection (the reference has none: a NaN loss just propagates, utils/custom_lbfgs.py:154).
+ * n_evals = loss+gradient evaluations since pinn_create; first_nonfinite_eval = 1-based number of the first one whose
+ * reduced loss was NaN/Inf, 0 if none.  Recording only: optimiser trajectories are unchanged.  When non-zero,
+ * pinn_last_error() carries a message too.  Either pointer may be NULL. */
+int pinn_get_status(pinn_ctx* c, int64_t* n_evals, int64_t* first_nonfinite_eval);
 
 /* Data-parallel: one process per GPU, RCCL all-reduce(SUM) of [grad | loss terms].
  * Rank 0 calls pinn_comm_unique_id and ships the 128 bytes to the other ranks by any
@@ -171,7 +185,7 @@ int pinn_comm_get_mode(pinn_ctx* c, int* mode);
  * [2] whole evaluation, [3] what an EMPTY event bracket reads on this stream (calibrated at
  * enable time; subtract it from [1..2] to compare with rocprofv3 kernel durations),
  * [4] = 1 when [0] is the exact begin-to-end duration of the single loss+grad kernel (the events
- * were attached to the launch itself, hipExtLaunchKernelGGL: kernel paths 1 and 2) and needs no correction;
+ * were attached to the launch itself, hipExtLaunchKernelGGL: kernel paths 1, 2 and 7) and needs no correction;
  * n = evaluations sampled. */
 int pinn_timing_enable(pinn_ctx* c, int max_evals, int every);
 int pinn_timing_read(pinn_ctx* c, double* avg_ms, int* n);

@@ -79,7 +79,7 @@ def run(hp):
 
     logger = Logger(hp)
     pinn = BurgersInformedNN(hp, logger, X_f, ub, lb, nu=0.01 / np.pi)
-    logger.set_error_fn(lambda: relative_l2(u_star, pinn.predict(X_star)[0]))
+    logger.set_error_fn(lambda: pinn.error_l2(X_star, u_star))     # = relative_l2(u_star, model(X_star)), on the device
     pinn.fit(X_u_train, u_train)
 
     u_pred = pinn.predict(X_star)[0]

@@ -86,10 +86,8 @@ if __name__ == "__main__":
     logger = Logger(hp)
     pinn = SchrodingerInformedNN(hp, logger, X_f, tb, ub, lb)
 
-    def error():
-        u_pred, v_pred = pinn.predict(X_star)
-        h_pred = np.sqrt(u_pred ** 2 + v_pred ** 2)
-        return np.linalg.norm(h_star - h_pred, 2) / np.linalg.norm(h_star, 2)
+    def error():      # ||h_star - |h_pred| ||_2 / ||h_star||_2 (:155-158), reduced on the device
+        return pinn.error_l2(X_star, h_star, modulus=True)
 
     logger.set_error_fn(error)
     # same call as the reference (:164): x0 is [N_0, 1]; see neuralnetwork._as_points

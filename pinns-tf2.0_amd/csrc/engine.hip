@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -25,6 +26,9 @@
 #include "kernels_sampling.h"
 #include "kernels_tile16.h"
 #include "kernels_xgmi.h"
+#include "kernels_predict20.h"
+
+#include <dlfcn.h>
 
 using namespace pinn;
 
@@ -65,6 +69,32 @@ static int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // ------------------------------------------------------------------------------------------
+// roctx ranges around the phases (the reference only prints wall-clock times, utils/logger.py:21-30):
+// librocprofiler-sdk-roctx is looked up lazily, so the engine has no hard dependency on it and a range costs one
+// predictable branch when no profiler is around.  rocprofv3 --marker-trace shows them as
+// pinn_adam_run / pinn_lbfgs_run / pinn_loss_grad / pinn_predict / pinn_error_l2.
+// ------------------------------------------------------------------------------------------
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (getenv("PINN_NO_ROCTX")) return;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static Roctx& roctx() { static Roctx r; return r; }
+struct Range {
+  bool on;
+  explicit Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~Range() { if (on) roctx().pop(); }
+};
+
+// ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
 static constexpr int CHUNK_POINTS = 32768;   // points per forward/backward launch pair
@@ -101,6 +131,17 @@ struct pinn_ctx {
   size_t cap_eval = 0;
   double* f_out = nullptr;
   size_t cap_f = 0;
+  // evaluation points / reference values of the last predict / error call, kept on the host (to recognise a repeat:
+  // the scripts evaluate the same X_star grid again and again) and on the device
+  std::vector<double> ev_X, ev_ref;
+  int ev_n_pad = 0;
+  double *pred = nullptr, *d_ref = nullptr, *err_partial = nullptr, *err_res = nullptr;
+  size_t cap_pred = 0, cap_ref = 0, cap_errp = 0;
+  double* h_err = nullptr;           // pinned [3]
+  // first evaluation (1-based count since pinn_create) whose reduced loss was not finite; 0 = none so far.
+  // The reference has no such guard (a NaN loss just propagates, custom_lbfgs.py:154); this only records it.
+  unsigned long long* d_nonfinite = nullptr;
+  unsigned long long n_evals = 0;
 
   // Adam
   double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-7;
@@ -154,6 +195,7 @@ struct pinn_ctx {
     int* err = nullptr;
     unsigned int seq = 0;                     // evaluation counter; 0 is never used (an all-zero mailbox is invalid)
     bool attached = false, on = false;
+    bool poisoned = false;                    // a peer was lost mid-step: weights / moments are a mix of two iterates
   } xg;
 
   // per-wave phase timeline of the fused kernel (profiling build only)
@@ -373,10 +415,11 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
   if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
-                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img);
+                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img, c->n_evals,
+                       c->d_nonfinite);
   else
     hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
-                       n_rows, c->R, c->gl);
+                       n_rows, c->R, c->gl, c->nd.n_theta, c->n_evals, c->d_nonfinite);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -680,6 +723,7 @@ static int disc_eval_any(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
 static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
   int rc = is_disc(c) ? disc_ensure(c) : ensure_sets(c);
   if (rc) return rc;
+  c->n_evals += 1;
   hipEvent_t* ev4 = nullptr;
   if (c->timing && c->ev_used < c->ev_cap_evals && (c->ev_seen++ % c->ev_every) == 0)
     ev4 = &c->ev[(size_t)4 * c->ev_used];
@@ -767,7 +811,11 @@ static int xg_check(pinn_ctx* c) {
   int e = 0;
   HIPCHK(hipMemcpyAsync(&e, c->xg.err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (e) return fail(PINN_ECOMM, "mailbox all-reduce: a peer did not deliver its vector within the time limit");
+  if (e) {
+    c->xg.poisoned = true;
+    return fail(PINN_ECOMM, "mailbox all-reduce: a peer did not deliver its vector within the time limit; the weights "
+                            "are undefined until pinn_set_weights");
+  }
   return 0;
 }
 
@@ -817,31 +865,83 @@ static int cast_weights(pinn_ctx* c) {
   return 0;
 }
 
-// Taylor-channel forward sweep over n caller-supplied points -> c->Oe ([n_out][n_pad] vec4 (u, u_x, u_t, u_xx))
-static int forward_eval(pinn_ctx* c, const double* X, int64_t n, int* n_pad_out) {
+// n caller-supplied points -> c->xe / c->te (compute dtype, padded to 64 with inert points).  The last point set stays
+// on the device and on the host: a repeat with identical contents (the scripts evaluate the same X_star grid at every
+// logged error and again at the end, utils/logger.py:56-60, inf_cont_burgers.py:114-123) uploads nothing.
+static int eval_points(pinn_ctx* c, const double* X, int64_t n, int* n_pad_out) {
   const size_t rs = real_size(c);
   const int NO = c->nd.n_out;
-  const size_t W = c->nd.width, H = c->nd.n_hidden;
   const int n_pad = (int)((n + 63) / 64 * 64);
-  const int chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
+  *n_pad_out = n_pad;
+  if ((size_t)n * 2 == c->ev_X.size() && c->ev_n_pad == n_pad && memcmp(c->ev_X.data(), X, (size_t)n * 16) == 0) return 0;
   if ((size_t)n_pad > c->cap_eval) {
     if (dev_alloc(&c->xe, n_pad * rs) || dev_alloc(&c->te, n_pad * rs) ||
         dev_alloc(&c->Oe, (size_t)NO * n_pad * 4 * rs)) return PINN_EHIP;
     c->cap_eval = n_pad;
   }
-  const size_t need_S = H * W * (size_t)chunk * 4 * rs;
-  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
+  c->ev_X.clear();
   std::vector<double> hx(n_pad, c->lb[0]), ht(n_pad, c->lb[1]);
   for (int64_t i = 0; i < n; ++i) { hx[i] = X[2 * i]; ht[i] = X[2 * i + 1]; }
   if (upload_real(c, c->xe, hx.data(), n_pad) || upload_real(c, c->te, ht.data(), n_pad)) return PINN_EHIP;
+  c->ev_X.assign(X, X + 2 * n);
+  c->ev_n_pad = n_pad;
+  return 0;
+}
+
+// width-20 nets: the MFMA forward sweeps of kernels_predict20.h.  NCH = 4 -> O4 ([n_pad] vec4 (u, u_x, u_t, u_xx)),
+// NCH = 1 -> out1 ([n_pad] float64 u)
+template <int NCH>
+static int predict20_launch(pinn_ctx* c, const void* xs, const void* ts, int n_pad, void* O4, double* out1) {
+  const int n_tiles = n_pad / 64;
+  const double sx = 2.0 / (c->ub[0] - c->lb[0]), st = 2.0 / (c->ub[1] - c->lb[1]);
+  if (c->dtype == PINN_F64) {
+    const size_t lds = predict20_lds_bytes(c->nd, 8);
+    const int wg = n_tiles < 4 * c->n_cu ? n_tiles : 4 * c->n_cu;
+    hipLaunchKernelGGL((k_fwd20d<NCH>), dim3(wg), dim3(256), lds, c->stream, c->nd, (const double*)c->theta_r,
+                       (const double*)xs, (const double*)ts, n_tiles, c->lb[0], c->lb[1], sx, st,
+                       (vec4<double>*)O4, out1);
+  } else {
+    const size_t lds = predict20_lds_bytes(c->nd, 4);
+    const int wg = n_tiles < 8 * c->n_cu ? n_tiles : 8 * c->n_cu;
+    hipLaunchKernelGGL((k_fwd20f<NCH>), dim3(wg), dim3(64), lds, c->stream, c->nd, (const float*)c->theta_r,
+                       (const float*)xs, (const float*)ts, n_tiles, (float)c->lb[0], (float)c->lb[1], (float)sx,
+                       (float)st, (vec4<float>*)O4, out1);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Taylor-channel forward sweep of the points in xs/ts -> O ([n_out][n_pad] vec4 (u, u_x, u_t, u_xx))
+static int forward_taylor(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int chunk, void* O) {
+  if (predict20_ok(c->nd) && !is_disc(c)) return predict20_launch<4>(c, xs, ts, n_pad, O, nullptr);
+  const size_t need_S = (size_t)c->nd.n_hidden * c->nd.width * (size_t)chunk * 4 * real_size(c);
+  if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
   for (int base = 0; base < n_pad; base += chunk) {
     const int pts = (n_pad - base < chunk) ? n_pad - base : chunk;
-    const int rc = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts)
-                                        : forward_chunk<float>(c, c->xe, c->te, n_pad, chunk, c->Oe, base, pts);
+    const int rc = c->dtype == PINN_F64 ? forward_chunk<double>(c, xs, ts, n_pad, chunk, O, base, pts)
+                                        : forward_chunk<float>(c, xs, ts, n_pad, chunk, O, base, pts);
     if (rc) return rc;
   }
   HIPCHK(hipGetLastError());
-  *n_pad_out = n_pad;
+  return 0;
+}
+
+// network outputs at the current evaluation points -> c->pred ([n][n_out] float64, device)
+static int predict_values(pinn_ctx* c, int64_t n, int n_pad) {
+  const int NO = c->nd.n_out;
+  if ((size_t)n_pad * NO > c->cap_pred) {
+    if (dev_alloc(&c->pred, (size_t)n_pad * NO * 8)) return PINN_EHIP;
+    c->cap_pred = (size_t)n_pad * NO;
+  }
+  if (predict20_ok(c->nd) && !is_disc(c)) return predict20_launch<1>(c, c->xe, c->te, n_pad, nullptr, c->pred);
+  const int chunk = n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS;
+  if (int rc = forward_taylor(c, c->xe, c->te, n_pad, chunk, c->Oe)) return rc;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (c->dtype == PINN_F64)
+    hipLaunchKernelGGL((k_pick_values<double>), grid, block, 0, c->stream, (const vec4<double>*)c->Oe, (int)n, n_pad, NO, c->pred);
+  else
+    hipLaunchKernelGGL((k_pick_values<float>), grid, block, 0, c->stream, (const vec4<float>*)c->Oe, (int)n, n_pad, NO, c->pred);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -851,7 +951,7 @@ static int forward_eval(pinn_ctx* c, const double* X, int64_t n, int* n_pad_out)
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err.c_str(); }
-int pinn_abi_version(void) { return 3; }
+int pinn_abi_version(void) { return 4; }
 
 int pinn_device_count(int* n) {
   REQUIRE(n, "null");
@@ -919,6 +1019,8 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   HIPCHK(hipMemsetAsync(c->theta, 0, n * 8, c->stream));
   HIPCHK(hipMemsetAsync(c->theta_r, 0, n * real_size(c), c->stream));
   HIPCHK(hipMemsetAsync(c->gl, 0, (size_t)c->R * 8, c->stream));
+  if (dev_alloc(&c->d_nonfinite, 8)) { delete c; return PINN_EHIP; }
+  HIPCHK(hipMemsetAsync(c->d_nonfinite, 0, 8, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   {
     hipDeviceProp_t prop;
@@ -963,11 +1065,13 @@ int pinn_destroy(pinn_ctx* c) {
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
-                  c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp};
+                  c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp,
+                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
   if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
   if (c->h_lb_log_iter) (void)hipHostFree(c->h_lb_log_iter);
+  if (c->h_err) (void)hipHostFree(c->h_err);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1062,12 +1166,16 @@ int pinn_set_weights(pinn_ctx* c, const double* w, int64_t n) {
   int rc = cast_weights(c);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->xg.poisoned = false;
   return 0;
 }
 
 int pinn_get_weights(pinn_ctx* c, double* w, int64_t n) {
   REQUIRE(c && w, "null");
   REQUIRE(n == c->nd.n_theta, "weight vector has %lld entries, expected %d", (long long)n, c->nd.n_theta);
+  if (c->xg.poisoned)
+    return fail(PINN_ESTATE, "the weights are undefined: a mailbox peer was lost in the middle of an optimiser step "
+                             "(PINN_ECOMM was returned); restore them with pinn_set_weights");
   HIPCHK(hipSetDevice(c->device));
   HIPCHK(hipMemcpyAsync(w, c->theta, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -1077,6 +1185,7 @@ int pinn_get_weights(pinn_ctx* c, double* w, int64_t n) {
 int pinn_loss_grad(pinn_ctx* c, double* loss, double* grad, double* terms) {
   REQUIRE(c, "null");
   HIPCHK(hipSetDevice(c->device));
+  const Range rg("pinn_loss_grad");
   int rc = eval_loss_grad(c);
   if (rc) return rc;
   std::vector<double> h(c->R);
@@ -1106,6 +1215,7 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
   REQUIRE(c->adam_ready, "pinn_adam_init has not been called");
   HIPCHK(hipSetDevice(c->device));
   if (n_steps == 0) return 0;
+  const Range rg("pinn_adam_run");
   if (losses && (size_t)n_steps > c->cap_loss_hist) {
     if (dev_alloc(&c->loss_hist, (size_t)n_steps * 3 * 8)) return PINN_EHIP;
     c->cap_loss_hist = n_steps;
@@ -1191,6 +1301,10 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     add(c->lb_S, (size_t)M1 * n); add(c->lb_Y, (size_t)M1 * n); add(c->lb_cs, M1); add(c->lb_cy, M1);
     add(c->lb_SY, (size_t)2 * M1 * M1); add(c->lb_YY, (size_t)2 * M1 * M1); add(c->lb_ro, (size_t)2 * M1);
     add(c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL)); add(c->lb_ex, sizeof(LbcExtra) / 8);
+    // the optimiser state starts as {0..., Hdiag = 1}: written by the same launch (no host buffer in flight)
+    static_assert(sizeof(LbfgsState) % 8 == 0 && offsetof(LbfgsState, Hdiag) % 8 == 0, "LbfgsState is initialised as doubles");
+    zl.state = (double*)c->lb_state; zl.state_doubles = (int)(sizeof(LbfgsState) / 8);
+    zl.hdiag_index = (int)(offsetof(LbfgsState, Hdiag) / 8);
     hipLaunchKernelGGL(k_zero_list, dim3(256), dim3(256), 0, c->stream, zl);
     HIPCHK(hipGetLastError());
   }
@@ -1201,9 +1315,6 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
       return PINN_EHIP;
     c->lb_cap_log = max_iter + 1;
   }
-  LbfgsState z{};
-  z.Hdiag = 1.0;
-  HIPCHK(hipMemcpyAsync(c->lb_state, &z, sizeof z, hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(c->lb_x, c->theta, n * 8, hipMemcpyDeviceToDevice, c->stream));
   int rc = eval_loss_grad(c);                                      // :65
   if (rc) return rc;
@@ -1232,6 +1343,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
   REQUIRE(c && n_iters >= 0, "bad arguments");
   REQUIRE(c->lb_ready, "pinn_lbfgs_begin has not been called");
   HIPCHK(hipSetDevice(c->device));
+  const Range rg("pinn_lbfgs_run");
   if (n_logged) *n_logged = 0;
   if (c->lb_max_iter == 0) { if (done) *done = 1; return 0; }
   const int n = c->nd.n_theta;
@@ -1328,19 +1440,56 @@ int pinn_predict(pinn_ctx* c, const double* X, int64_t n, double* out) {
   if (n == 0) return 0;
   if (is_disc(c))
     return disc_predict_any(c, 0, 0, X, n, out);
-  const size_t rs = real_size(c);
-  const int NO = c->nd.n_out;
+  const Range rg("pinn_predict");
   int n_pad = 0;
-  if (int rc = forward_eval(c, X, n, &n_pad)) return rc;
-  std::vector<char> ho((size_t)NO * n_pad * 4 * rs);
-  HIPCHK(hipMemcpyAsync(ho.data(), c->Oe, ho.size(), hipMemcpyDeviceToHost, c->stream));
+  if (int rc = eval_points(c, X, n, &n_pad)) return rc;
+  if (int rc = predict_values(c, n, n_pad)) return rc;
+  HIPCHK(hipMemcpyAsync(out, c->pred, (size_t)n * c->nd.n_out * 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int o = 0; o < NO; ++o)
-    for (int64_t i = 0; i < n; ++i) {
-      const size_t idx = ((size_t)o * n_pad + i) * 4;   // .x of vec4
-      out[(size_t)i * NO + o] = c->dtype == PINN_F64 ? ((const double*)ho.data())[idx]
-                                                     : (double)((const float*)ho.data())[idx];
-    }
+  return 0;
+}
+
+int pinn_error_l2(pinn_ctx* c, const double* X, const double* ref, int64_t n, int kind, double* err) {
+  REQUIRE(c && X && ref && err && n >= 1, "bad arguments");
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (element-wise over [n][n_out]) or 1 (modulus of the outputs against ref [n])");
+  REQUIRE(!is_disc(c), "pinn_error_l2: not defined for discrete-time models");
+  HIPCHK(hipSetDevice(c->device));
+  const Range rg("pinn_error_l2");
+  const int NO = c->nd.n_out;
+  const size_t n_ref = kind == 1 ? (size_t)n : (size_t)n * NO;
+  int n_pad = 0;
+  if (int rc = eval_points(c, X, n, &n_pad)) return rc;
+  if (c->ev_ref.size() != n_ref || memcmp(c->ev_ref.data(), ref, n_ref * 8) != 0) {
+    c->ev_ref.clear();
+    if (n_ref > c->cap_ref) { if (dev_alloc(&c->d_ref, n_ref * 8)) return PINN_EHIP; c->cap_ref = n_ref; }
+    HIPCHK(hipMemcpyAsync(c->d_ref, ref, n_ref * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->ev_ref.assign(ref, ref + n_ref);
+  }
+  if (int rc = predict_values(c, n, n_pad)) return rc;
+  const int nb = (int)((n_ref + ERR_SPAN - 1) / ERR_SPAN);
+  if ((size_t)nb > c->cap_errp) { if (dev_alloc(&c->err_partial, (size_t)nb * 16)) return PINN_EHIP; c->cap_errp = nb; }
+  if (!c->err_res && dev_alloc(&c->err_res, 3 * 8)) return PINN_EHIP;
+  if (!c->h_err) HIPCHK(hipHostMalloc((void**)&c->h_err, 3 * 8, hipHostMallocDefault));
+  hipLaunchKernelGGL(k_err_partial, dim3(nb), dim3(ERR_THREADS), 0, c->stream, (const double*)c->pred,
+                     (const double*)c->d_ref, (long long)n_ref, NO, kind, c->err_partial);
+  hipLaunchKernelGGL(k_err_final, dim3(1), dim3(64), 0, c->stream, (const double*)c->err_partial, nb, c->err_res);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->h_err, c->err_res, 3 * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  *err = c->h_err[0];
+  return 0;
+}
+
+int pinn_get_status(pinn_ctx* c, int64_t* n_evals, int64_t* first_nonfinite_eval) {
+  REQUIRE(c, "null");
+  HIPCHK(hipSetDevice(c->device));
+  unsigned long long nf = 0;
+  HIPCHK(hipMemcpyAsync(&nf, c->d_nonfinite, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (n_evals) *n_evals = (int64_t)c->n_evals;
+  if (first_nonfinite_eval) *first_nonfinite_eval = (int64_t)nf;
+  if (nf) fail(PINN_OK, "loss became non-finite at evaluation %llu of %llu", nf, c->n_evals);   // message only
   return 0;
 }
 
@@ -1387,16 +1536,7 @@ int pinn_residual(pinn_ctx* c, double* f, int64_t n) {
   if (cnt == 0) return 0;
   const int NO = c->nd.n_out;
   if ((size_t)cnt * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)cnt * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)cnt * NO; }
-  {  // the forward sweep below stashes one chunk of Taylor channels (the fused paths keep none)
-    const size_t need_S = (size_t)c->nd.n_hidden * c->nd.width * (size_t)c->chunk * 4 * real_size(c);
-    if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
-  }
-  for (int base = 0; base < sd.n_pad; base += c->chunk) {
-    const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
-    const int rc2 = c->dtype == PINN_F64 ? forward_chunk<double>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts)
-                                         : forward_chunk<float>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts);
-    if (rc2) return rc2;
-  }
+  if (int rc2 = forward_taylor(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O)) return rc2;
   const dim3 grid((cnt + 255) / 256), block(256);
 #define RES(REAL, P) hipLaunchKernelGGL((k_residual<REAL, P>), grid, block, 0, c->stream, first, cnt, sd.n_pad, (const vec4<REAL>*)c->O, (const REAL*)c->theta_r, c->nd.n_net, (REAL)c->nu, c->f_out, NO)
   if (c->dtype == PINN_F64) { if (c->pde == 0) RES(double, 0); else if (c->pde == 1) RES(double, 1); else RES(double, 2); }
@@ -1415,7 +1555,8 @@ int pinn_residual_at(pinn_ctx* c, const double* X, int64_t n, double* f) {
   if (n == 0) return 0;
   const int NO = c->nd.n_out;
   int n_pad = 0;
-  if (int rc = forward_eval(c, X, n, &n_pad)) return rc;
+  if (int rc = eval_points(c, X, n, &n_pad)) return rc;
+  if (int rc = forward_taylor(c, c->xe, c->te, n_pad, n_pad < CHUNK_POINTS ? n_pad : CHUNK_POINTS, c->Oe)) return rc;
   if ((size_t)n * NO > c->cap_f) { if (dev_alloc(&c->f_out, (size_t)n * NO * 8)) return PINN_EHIP; c->cap_f = (size_t)n * NO; }
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
 #define RES(REAL, P) hipLaunchKernelGGL((k_residual<REAL, P>), grid, block, 0, c->stream, 0, (int)n, n_pad, (const vec4<REAL>*)c->Oe, (const REAL*)c->theta_r, c->nd.n_net, (REAL)c->nu, c->f_out, NO)
@@ -1516,7 +1657,8 @@ int pinn_comm_benchmark(pinn_ctx* c, int mode, int iters, double* us_per_iter) {
   const dim3 grid((R + RED_COLS - 1) / RED_COLS), block(RED_THREADS);
   auto once = [&]() -> int {
     if (mode == 1) {
-      hipLaunchKernelGGL((k_reduce_rows<double>), grid, block, 0, c->stream, (const double*)vec, 1, R, out);
+      hipLaunchKernelGGL((k_reduce_rows<double>), grid, block, 0, c->stream, (const double*)vec, 1, R, out, 0, 0ull,
+                         (unsigned long long*)nullptr);
       NCCLCHK(ncclAllReduce(out, out, (size_t)R, ncclDouble, ncclSum, c->comm, c->stream));
     } else {
       if (++c->xg.seq == 0) c->xg.seq = 2;

@@ -48,13 +48,23 @@ __device__ __forceinline__ double reduce_column(const real* __restrict__ part, i
   return tot;
 }
 
+// Non-finite guard (SURVEY 5 "failure detection"; the reference has none: a NaN loss just propagates,
+// utils/custom_lbfgs.py:154).  The thread that owns a loss slot records the number of the first evaluation whose
+// reduced loss part is not finite; nothing else changes, the trajectory stays the reference's.
+__device__ __forceinline__ void note_nonfinite(double g, int c, int n_theta, unsigned long long eval_no,
+                                               unsigned long long* __restrict__ nonfinite) {
+  if (nonfinite && c >= n_theta && c < n_theta + 3 && !isfinite(g)) atomicCAS(nonfinite, 0ull, eval_no);
+}
+
 template <typename real>
 __global__ __launch_bounds__(RED_THREADS) void k_reduce_rows(const real* __restrict__ part, int n_rows,
-                                                             int R, double* __restrict__ gl) {
+                                                             int R, double* __restrict__ gl, int n_theta = 0,
+                                                             unsigned long long eval_no = 0,
+                                                             unsigned long long* __restrict__ nonfinite = nullptr) {
   __shared__ double sh[RED_SLICES][RED_COLS];
   const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const double g = reduce_column(part, n_rows, R, c, q, sh);
-  if (q == 0 && c < R) gl[c] = g;
+  if (q == 0 && c < R) { gl[c] = g; note_nonfinite(g, c, n_theta, eval_no, nonfinite); }
 }
 
 // Single-GPU Adam step fused behind the reduction (no all-reduce in between): same arithmetic as
@@ -67,12 +77,15 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_adam(const real* __restr
                                                              double* __restrict__ m, double* __restrict__ v,
                                                              double alpha, double b1, double b2, double eps,
                                                              double* __restrict__ loss3, NetDesc nd,
-                                                             float* __restrict__ img) {
+                                                             float* __restrict__ img,
+                                                             unsigned long long eval_no = 0,
+                                                             unsigned long long* __restrict__ nonfinite = nullptr) {
   __shared__ double sh[RED_SLICES][RED_COLS];
   const int c = blockIdx.x * RED_COLS + (threadIdx.x & 63), q = threadIdx.x >> 6;
   const double g = reduce_column(part, n_rows, R, c, q, sh);
   if (q != 0 || c >= R) return;
   gl[c] = g;
+  note_nonfinite(g, c, n, eval_no, nonfinite);
   if (c < n) {
     const double mi = m[c] + (1.0 - b1) * (g - m[c]);
     const double vi = v[c] + (1.0 - b2) * (g * g - v[c]);
@@ -322,8 +335,12 @@ struct ZeroList {
   double* p[10];
   unsigned long long n[10];     // doubles
   int count;
+  double* state;                // LbfgsState as doubles: all zero except Hdiag = 1 (custom_lbfgs.py:91-95), one thread
+  int state_doubles, hdiag_index;
 };
 __global__ __launch_bounds__(256) void k_zero_list(ZeroList zl) {
+  if (zl.state && blockIdx.x == 0 && threadIdx.x == 0)
+    for (int i = 0; i < zl.state_doubles; ++i) zl.state[i] = i == zl.hdiag_index ? 1.0 : 0.0;
   for (int a = 0; a < zl.count; ++a) {
     double* __restrict__ p = zl.p[a];
     const unsigned long long n = zl.n[a];

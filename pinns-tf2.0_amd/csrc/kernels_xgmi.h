@@ -86,8 +86,11 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
     }
     tot += __longlong_as_double((long long)(((unsigned long long)line.z << 32) | line.x));
   }
-  if (lost) return;                           // leave gl, the weights and the Adam moments untouched; the host
-                                              // sees err at its next synchronisation (xg_check) and raises
+  if (lost) return;                           // this COLUMN keeps its old gl / weight / moments; columns whose lines did
+                                              // arrive are updated, so after a lost peer the model state is a mix of two
+                                              // iterates: the host sees err at its next synchronisation (xg_check), raises
+                                              // PINN_ECOMM and marks the context's weights undefined (pinn_get_weights
+                                              // refuses until pinn_set_weights)
   gl[c] = tot;
   if (ADAM) {
     if (c < n) {

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h",
+SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h", "kernels_predict20.h",
            "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
@@ -31,50 +31,77 @@ class PinnNativeError(RuntimeError):
     pass
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+UNITS = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])]
+
+
+def _build_tag():
+    """what a library was built from, besides file times: the flags (an ablation / stamps build shares the sources)"""
+    return " ".join(COMMON_FLAGS) + " | " + " ; ".join("%s %s" % (u, " ".join(f)) for u, f in UNITS)
+
+
+def _stale(lib=None):
+    lib = lib or LIB_PATH
+    if not os.path.exists(lib):
         return True
-    built = os.path.getmtime(LIB_PATH)
+    built = os.path.getmtime(lib)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES] + [HEADER]
-    return any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs)
+    if any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs):
+        return True
+    tag = lib + ".flags"
+    return os.path.exists(tag) and open(tag).read().split("\n")[0] != _build_tag()
 
 
 def build(force=False, verbose=False, stamps=False):
     """Compile the HIP engine for gfx950 into pinn_native/libpinn_hip.so (in-tree, so the
     shared object travels with the repo snapshot).  hipcc cross-compiles without a GPU.
-    stamps=True builds the profiling variant libpinn_hip_stamps.so (-DPINN_STAMPS) instead."""
+    stamps=True builds the profiling variant libpinn_hip_stamps.so (-DPINN_STAMPS) instead.
+    Safe against concurrent callers (several ranks importing at once): a file lock serialises them, objects go to
+    a private temporary directory, the library is moved into place atomically."""
+    import fcntl
+    import tempfile
     out = LIB_PATH.replace(".so", "_stamps.so") if stamps else LIB_PATH
     if not force and not stamps and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
-    # two translation units (compiled concurrently), one shared object: k_fused20d wants its matrix results in
-    # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
-    if stamps:
-        common.append("-DPINN_STAMPS")
-    tag = "_stamps" if stamps else ""
-    units = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])]
-    objs, procs = [], []
-    for src, extra in units:
-        obj = os.path.join(_HERE, os.path.splitext(src)[0] + tag + ".o")
-        cmd = common + extra + ["-c", os.path.join(_CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        log = pr.communicate()[0]
-        if pr.returncode != 0:
-            raise PinnNativeError("hipcc failed (%s):\n%s" % (" ".join(cmd), log))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp", "-lrccl"]
-    if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise PinnNativeError("hipcc link failed:\n" + res.stdout + res.stderr)
-    os.replace(out + ".tmp", out)
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not stamps and not _stale():        # another process built it while we waited
+            return LIB_PATH
+        # two translation units (compiled concurrently), one shared object: k_fused20d wants its matrix results in
+        # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation
+        common = [hipcc] + COMMON_FLAGS + (["-DPINN_STAMPS"] if stamps else [])
+        with tempfile.TemporaryDirectory(prefix="pinn_build_", dir=_HERE) as tmp:
+            objs, procs = [], []
+            for src, extra in UNITS:
+                obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+                cmd = common + extra + ["-c", os.path.join(_CSRC, src), "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+                objs.append(obj)
+            failures = []
+            for cmd, pr in procs:                              # wait for ALL compiles before reporting
+                log = pr.communicate()[0]
+                if pr.returncode != 0:
+                    failures.append("hipcc failed (%s):\n%s" % (" ".join(cmd), log))
+            if failures:
+                raise PinnNativeError("\n".join(failures))
+            tmp_so = os.path.join(tmp, "lib.so")
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp_so, "-lrccl"]
+            if verbose:
+                print(" ".join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise PinnNativeError("hipcc link failed:\n" + res.stdout + res.stderr)
+            os.replace(tmp_so, out)
+            for obj in objs:                                   # kept for the ablation builds of profiles/ (relinked there)
+                os.replace(obj, os.path.join(_HERE, os.path.basename(obj).replace(".o", "_stamps.o" if stamps else ".o")))
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+        with open(out + ".flags", "w") as fh:                  # flags + the compiler the kernels were validated with
+            fh.write(_build_tag() + ("\n-DPINN_STAMPS" if stamps else "") + "\n" + "\n".join(ver[:3]) + "\n")
     return out
 
 
@@ -113,6 +140,10 @@ _SIGNATURES = {
     "pinn_lbfgs_get_x": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
+    "pinn_error_l2": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, _c_double_p, ctypes.c_int64, ctypes.c_int,
+                                     _c_double_p]),
+    "pinn_get_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64),
+                                       ctypes.POINTER(ctypes.c_int64)]),
     "pinn_residual": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_residual_at": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
     "pinn_comm_xgmi_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_char_p]),
@@ -321,6 +352,24 @@ class Engine(object):
         out = np.empty((X.shape[0], self.n_out), dtype=np.float64)
         self._check(self._lib.pinn_predict(self._h, _dp(X), X.shape[0], _dp(out)))
         return out
+
+    def error_l2(self, X, ref, modulus=False):
+        """||ref - model(X)||_2 / ||ref||_2 reduced on the device (the scripts' error metric).  modulus=True compares
+        |h| = sqrt(sum_o out_o^2) with ref [n] (Schrodinger)."""
+        X = _f64(X).reshape(-1, self.n_in)
+        ref = _f64(ref).reshape(-1) if modulus else _f64(ref).reshape(X.shape[0], self.n_out)
+        if ref.shape[0] != X.shape[0]:
+            raise ValueError("ref must hold one row per point")
+        err = ctypes.c_double(0.0)
+        self._check(self._lib.pinn_error_l2(self._h, _dp(X), _dp(ref), X.shape[0], 1 if modulus else 0,
+                                            ctypes.byref(err)))
+        return err.value
+
+    def status(self):
+        """(loss+grad evaluations so far, 1-based number of the first one with a non-finite loss or 0)"""
+        n, bad = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._check(self._lib.pinn_get_status(self._h, ctypes.byref(n), ctypes.byref(bad)))
+        return n.value, bad.value
 
     def residual(self):
         n = self.n_u if self.pde == "burgers_ide" else self.n_f

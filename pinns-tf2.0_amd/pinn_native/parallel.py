@@ -57,6 +57,16 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
         mailbox = policy != "rccl"
     engine.comm_probe_us = None
     if not mailbox:
+        # what one exchange of the [P+4] vector costs on this node (k_reduce_rows + ncclAllReduce, wall time per
+        # iteration, MAX over ranks): the number the 8-GPU budget of DESIGN.md 6 needs.  Collective, every rank calls it.
+        try:
+            mine = engine.comm_benchmark("rccl")
+        except PinnNativeError:
+            mine = None
+        probes = [None] * world
+        dist.all_gather_object(probes, mine)
+        if all(p is not None for p in probes):
+            engine.comm_probe_us = {"rccl": max(probes)}
         return "rccl"
     try:
         mine = engine.comm_xgmi_export(world, rank)

@@ -160,10 +160,14 @@ class NeuralNetwork(object):
         engine's canonical initial vector), or from a private RandomState(hp["seed"]) when that key is given."""
         from scipy.stats import truncnorm
         rs = np.random.RandomState(int(hp["seed"])) if "seed" in hp else _init_stream()
+        # hp["init_scale"] (diagnostic): every initial kernel multiplied by it -- how the ulp-perturbation ensembles of
+        # tests/golden/make_band.py are reproduced on the GPU (tests/test_gpu_end_to_end.py)
+        scale = float(hp.get("init_scale", 1.0))
         chunks = []
         for fi, fo in zip(self.layers[:-1], self.layers[1:]):
             sigma = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
-            chunks.append((truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel())
+            chunks.append((truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel() * scale
+                          if scale != 1.0 else (truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel())
             chunks.append(np.zeros(fo))
         chunks.append(self._extra_params())
         return np.concatenate(chunks)
@@ -173,16 +177,24 @@ class NeuralNetwork(object):
         """Plain data misfit, as the base class of the reference (neuralnetwork.py:51-52)."""
         return float(np.mean(np.square(np.asarray(u) - np.asarray(u_pred))))
 
-    def _bind(self, X, u):
-        X = _as_points(X, self)
-        u = np.asarray(u, dtype=np.float64).reshape(X.shape[0], -1)
+    @staticmethod
+    def _digest(X, u):
         h = hashlib.blake2b(digest_size=16)          # full-buffer digest: a few ms at 1e6 points
         h.update(np.ascontiguousarray(X).tobytes())
         h.update(np.ascontiguousarray(u).tobytes())
-        key = (X.shape, u.shape, h.digest())
+        return (X.shape, u.shape, h.digest())
+
+    def _bind(self, X, u, key=None):
+        """make (X, u) the engine's data set unless it already is; `key` = a digest computed earlier for exactly
+        these (private, unchanged) arrays, so that a closure does not re-hash its data on every evaluation"""
+        X = _as_points(X, self)
+        u = np.asarray(u, dtype=np.float64).reshape(X.shape[0], -1)
+        if key is None:
+            key = self._digest(X, u)
         if key != self._bound:
             self._engine.set_data(X, u)
             self._bound = key
+        return key
 
     def _split(self, flat):
         out, off = [], 0
@@ -230,10 +242,13 @@ class NeuralNetwork(object):
         self.set_weights(w)
 
     def get_loss_and_flat_grad(self, X, u):
-        self._bind(X, u)
+        # the closure owns private copies of its data (like the reference's immutable tensors), hashed once here
+        Xc = np.array(_as_points(X, self), dtype=np.float64)
+        uc = np.array(u, dtype=np.float64).reshape(Xc.shape[0], -1)
+        key = self._bind(Xc, uc)
 
         def loss_and_flat_grad(w):
-            self._bind(X, u)             # the closure evaluates ITS data, whatever was bound in between
+            self._bind(Xc, uc, key)      # the closure evaluates ITS data, whatever was bound in between
             self.set_weights(w)
             loss_value, flat, _ = self._engine.loss_grad()
             return loss_value, flat
@@ -303,9 +318,24 @@ class NeuralNetwork(object):
         self.tf_optimization(X_u, u)
         self.nt_optimization(X_u, u)
         self.logger.log_train_end(self.tf_epochs + self.nt_config.maxIter)
+        bad = self._engine.status()[1]
+        if bad:
+            print("warning: the loss became non-finite at evaluation %d" % bad, file=sys.stderr)
 
     def predict(self, X_star):
         return self._engine.predict(_as_points(X_star, self))
+
+    def error_l2(self, X_star, reference, modulus=False):
+        """The scripts' error metric ||reference - model(X_star)||_2 / ||reference||_2
+        (1d-burgers/inf_cont_burgers.py:114-116 through utils/logger.py:56-60), reduced on the device: the grid and
+        the reference field are uploaded once, 24 bytes come back.  modulus=True compares |h| of a two-output
+        model with reference [n] (1dcomplex-schrodinger/inf_cont_schrodinger.py:155-158)."""
+        return self._engine.error_l2(_as_points(X_star, self), reference, modulus=modulus)
+
+    def status(self):
+        """(evaluations so far, number of the first evaluation whose loss was NaN/Inf or 0): the reference has no
+        such guard, a NaN just propagates (utils/custom_lbfgs.py:154)"""
+        return self._engine.status()
 
     def summary(self):
         return self.model.summary()

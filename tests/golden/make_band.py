@@ -16,10 +16,12 @@ evidence, all written here:
   burgers_prefix.npz       k = 0, *shortened* schedules where float64 implementations still track each other:
                            weights, field and error after (100 Adam), (100 Adam + 50 L-BFGS), (100 Adam + 100 L-BFGS)
                            -- what the GPU float64 run is compared with, field by field
+  burgers_band_eps32.json  the cfg-2 ensemble again with float32-sized perturbations (1 + k 2^-23): what the float32
+                           engine's own ensemble is ranked against
   burgers_cfg1_band.json   BASELINE configs[0]: Adam x 2000 at lr 0.03, no L-BFGS (reference value 4.3073e-01):
                            printed log of the k = 0 run + the same ulp band
 
-    python3 tests/golden/make_band.py [cfg2] [prefix] [cfg1]
+    python3 tests/golden/make_band.py [cfg2] [cfg2_eps32] [prefix] [cfg1]
 """
 import json
 import os
@@ -31,14 +33,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden as mg  # noqa: E402
 
-K_ULP = [0, 1, -1, 2, 3, -2, -3, 4, -4]          # configs[0] (76 s per run)
-K_ULP_CFG2 = K_ULP                              # configs[1] (15 s per run): the same 9-member ensemble
+# 25 members per ensemble (round 3; rounds 1-2 had the first nine): k = 0, +-1 ... +-12
+K_ULP = [0, 1, -1, 2, 3, -2, -3, 4, -4] + [s * k for k in range(5, 13) for s in (1, -1)]   # configs[0] (76 s per run)
+K_ULP_CFG2 = K_ULP                              # configs[1] (15 s per run)
 EPS = 2.0 ** -52
+EPS32 = 2.0 ** -23                               # float32-sized perturbations (what the float32 engine is compared with)
 
 
-def run(hp, k):
+def run(hp, k, eps=EPS):
     import tensorflow as tf
-    tf._INIT_SCALE[0] = 1.0 + k * EPS
+    tf._INIT_SCALE[0] = 1.0 + k * eps
     try:
         g, out = mg.run_reference_script("1d-burgers/inf_cont_burgers.py", hp)
     finally:
@@ -49,11 +53,25 @@ def run(hp, k):
     return dict(final_error=float(g["error"]()), lines=lines, w=pinn.get_weights().numpy(), u_pred=u_pred[:, 0])
 
 
-def band(name, hp, fields_file=None, ks=K_ULP):
-    rec = {"hp": hp, "k_ulp": ks, "scale": "every initial Dense kernel multiplied by (1 + k * 2**-52)", "runs": {}}
+def band(name, hp, fields_file=None, ks=K_ULP, eps=EPS):
+    """(re)writes <name>.json; members already present in the file (same hp, same perturbation unit) are kept, so
+    an ensemble can be grown without re-running its earlier members"""
+    bits = int(round(-np.log2(eps)))
+    rec = {"hp": hp, "k_ulp": ks, "eps": eps,
+           "scale": "every initial Dense kernel multiplied by (1 + k * 2**-%d)" % bits, "runs": {}}
     fields = {}
+    path = os.path.join(HERE, name + ".json")
+    if os.path.exists(path):
+        old = json.load(open(path))
+        if old.get("hp") == hp and old.get("eps", EPS) == eps:
+            rec["runs"] = {k: v for k, v in old["runs"].items() if int(k) in ks}
+            if fields_file and os.path.exists(os.path.join(HERE, fields_file)):
+                with np.load(os.path.join(HERE, fields_file)) as f:
+                    fields = {k: f[k] for k in f.files}
     for k in ks:
-        r = run(hp, k)
+        if str(k) in rec["runs"] and ("u_k%+d" % k in fields or not fields_file):
+            continue
+        r = run(hp, k, eps)
         rec["runs"][str(k)] = {"final_error": r["final_error"], "lines": r["lines"] if k == 0 else r["lines"][-3:],
                                "w_sha": mg.sha16(r["w"])}
         fields["u_k%+d" % k] = r["u_pred"][::5].astype(np.float32)
@@ -64,7 +82,8 @@ def band(name, hp, fields_file=None, ks=K_ULP):
     errs = [v["final_error"] for v in rec["runs"].values()]
     rec["band"] = [min(errs), max(errs)]
     rec["reference_final_error"] = rec["runs"]["0"]["final_error"]
-    with open(os.path.join(HERE, name + ".json"), "w") as f:
+    rec["runs"] = {str(k): rec["runs"][str(k)] for k in ks}
+    with open(path, "w") as f:
         json.dump(rec, f, indent=1)
     if fields_file:
         np.savez_compressed(os.path.join(HERE, fields_file), **fields)
@@ -88,9 +107,13 @@ def main():
     sys.path.insert(0, mg.SHIMS)
     sys.path.insert(1, os.path.join(mg.REF, "utils"))
     sys.path.insert(2, os.path.join(mg.REF, "1d-burgers"))
-    which = sys.argv[1:] or ["cfg2", "prefix", "cfg1"]
+    which = sys.argv[1:] or ["cfg2", "cfg2_eps32", "prefix", "cfg1"]
     if "cfg2" in which:
         band("burgers_band", mg.burgers_hp(tf_epochs=100, nt_epochs=200), "burgers_band_fields.npz", K_ULP_CFG2)
+    if "cfg2_eps32" in which:
+        # the same schedule under float32-sized perturbations of the initial kernels: the ensemble a float32
+        # implementation of the path belongs to (its own rounding is a perturbation of that size at every step)
+        band("burgers_band_eps32", mg.burgers_hp(tf_epochs=100, nt_epochs=200), None, K_ULP_CFG2, EPS32)
     if "prefix" in which:
         prefix()
     if "cfg1" in which:

@@ -36,6 +36,8 @@ def main():
         eng.set_pde_params(NU)
         mode = init_engine_comm(eng, dist, world, rank, mailbox=True, rccl=False)
         assert mode == "mailbox" and eng.comm_mode() == "mailbox", mode
+        # the families bench.py --gpus N launches: k_fused20d (path 7) in float64, k_fused20m (path 2) in float32
+        assert eng.kernel_path() == (7 if dtype == "f64" else 2), eng.kernel_path()
         ref = pinn_native.Engine(LAYERS, lb, ub, pde="burgers", dtype=dtype, device=0)
         ref.set_collocation(X_f); ref.set_data(X_u, u); ref.set_pde_params(NU)
         for e in (eng, ref):

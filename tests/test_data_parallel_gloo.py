@@ -229,6 +229,8 @@ class _StubEngine(object):
     def timing_enable(self, n, every=1): pass
     def timing_read(self): return {"fwd_ms": 0.03, "sweeps_ms": 0.03, "eval_ms": 0.04, "empty_bracket_ms": 0.005, "kernel_exact": True, "n": 32}
     def predict(self, X): return np.zeros((len(X), 1))
+    def error_l2(self, X, ref, modulus=False): return 0.25
+    def comm_benchmark(self, mode, iters=200): return 21.0
     def comm_init(self, uid, world, rank): self.comm = (bytes(uid), world, rank)
     def comm_set_mode(self, m): pass
     def close(self): pass
@@ -244,6 +246,7 @@ def _bench_main_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK=str(rank))
     os.environ.pop("PINN_COMM", None)
+    os.environ["PINN_BENCH_MIN_TIMED_MS"] = "20"          # the product default (3 s per leg) is for real GPUs
     import contextlib
     import io
     import pinn_native
@@ -278,11 +281,14 @@ def test_bench_main_world2_emits_one_contract_line(tmp_path):
     assert j["vs_baseline"] is None and j["cpu_baseline"] is None and j["higher_is_better"] is True
     assert j["config"]["n_f_total"] == 10000 and j["config"]["n_f_per_gpu"] == 5000 and j["config"]["parallelism"] == "dp2"
     assert j["config"]["allreduce"] == "rccl" and j["config"]["replicas_identical"] is True
+    assert j["config"]["allreduce_probe_us"] == {"rccl": 21.0}       # probed at every N > 1, RCCL default included
+    assert j["dtype"] == "f64" and j["roofline"]["peak"] == 78.6     # headline = the reference's arithmetic
+    assert "burgers_shock.mat" in j["data"] and j["final_l2_error_abs_delta"] is not None
     assert abs(j["value"] - 10000 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in j["roofline"]
     assert j["cfg5_leg"]["n_f_total"] == 1000000 and j["cfg5_leg"]["n_f_per_gpu"] == 500000
-    assert j["float64_leg"]["dtype"] == "f64" and j["float64_leg"]["kernel_path"] == 7
+    assert j["float32_leg"]["dtype"] == "f32" and j["float32_leg"]["kernel_path"] == 2
     for r in range(2):
         sets = open(tmp_path / ("rank%d.sets" % r)).read().split(";")
-        assert sets == ["f32:5000:(2, %d)" % r, "f64:5000:(2, %d)" % r, "f32:500000:(2, %d)" % r], sets
+        assert sets == ["f64:5000:(2, %d)" % r, "f32:5000:(2, %d)" % r, "f64:500000:(2, %d)" % r], sets

@@ -139,7 +139,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(pinn_native.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pinn_abi_version() == 3
+    assert lib.pinn_abi_version() == 4
     # plain C types only in the header
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
     assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
