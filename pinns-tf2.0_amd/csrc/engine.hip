@@ -2,7 +2,8 @@
 // of the MI355X PINN engine.  Built for gfx950 only:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -c engine.hip
 //   hipcc ... -mllvm -amdgpu-mfma-vgpr-form=1 -fPIC -c fused20d_unit.hip          (see fused20d_api.h)
-//   hipcc --offload-arch=gfx950 -shared -fPIC engine.o fused20d_unit.o -o libpinn_hip.so -lrccl
+//   hipcc ... -fPIC -c fused20m_unit.hip                                              (see fused20m_api.h)
+//   hipcc --offload-arch=gfx950 -shared -fPIC engine.o fused20d_unit.o fused20m_unit.o -o libpinn_hip.so -lrccl
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -19,6 +20,7 @@
 #include "kernels_fused20.h"
 #include "kernels_fused20m.h"
 #include "fused20d_api.h"
+#include "fused20m_api.h"
 #include "kernels_wide.h"
 #include "kernels_generic.h"
 #include "kernels_optim.h"
@@ -223,13 +225,13 @@ static bool fused_ok(const pinn_ctx* c) {
 // the register-stash kernel: float32, width 20, instantiated depths, weights + tiles within LDS
 static bool fused_regs_ok(const pinn_ctx* c) {
   return c->dtype == PINN_F32 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER && !is_disc(c) &&
-         c->nd.n_hidden == 8 && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
+         fused20m_depth_ok(c->nd.n_hidden) && fused20m_lds_bytes(c->nd.n_hidden) <= 160 * 1024;
 }
 
 // the float64 register-stash kernel (kernels_fused20d.h): float64, width 20, 8 hidden layers, Burgers problems
 static bool fused_f64_ok(const pinn_ctx* c) {
   return c->dtype == PINN_F64 && fused20_supported(c->nd) && c->pde != PINN_PDE_SCHRODINGER && !is_disc(c) &&
-         c->nd.n_hidden == 8 && fused20d_lds_bytes(c->nd.n_hidden, c->nd.n_theta) <= 160 * 1024;
+         fused20d_depth_ok(c->nd.n_hidden) && fused20d_lds_bytes(c->nd.n_hidden, c->nd.n_theta) <= 160 * 1024;
 }
 
 // the wide MFMA sweeps: float32, hidden width 100, two outputs (the Schrodinger net)
@@ -506,11 +508,18 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     if (rc) return fail(PINN_EHIP, "fused20d launch failed: %s", hipGetErrorString((hipError_t)rc));
   } else if (c->path == 2) {
     int rc = hipErrorInvalidValue;
-    if constexpr (sizeof(real) == 4 && PDE != 2)
-      rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+    if constexpr (sizeof(real) == 4 && PDE != 2) {
+      if (c->nd.n_hidden == 8)
+        rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+                                     (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
+                                     (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
+                                     c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
+      else        // depths 4, 6, 10: fused20m_unit.hip
+        rc = fused20m_launch_depth(PDE, c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
                                    (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
                                    (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
                                    c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
+    }
     if (rc) return fail(PINN_EHIP, "fused20m launch failed: %s", hipGetErrorString((hipError_t)rc));
   } else if (c->path == 1) {
     const int rc = fused20_launch<real, PDE>(c->nd, sd, (const real*)c->theta_r, (const real*)c->xs,
@@ -1758,12 +1767,12 @@ int pinn_set_kernel_path(pinn_ctx* c, int path) {
           "7 (fused width-20 float64, register stash)");
   if (path >= 4 && path <= 6) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
   if (path == 7)
-    REQUIRE(fused_f64_ok(c), "the float64 register-stash path needs float64, hidden width 20, 8 hidden layers and a Burgers problem");
+    REQUIRE(fused_f64_ok(c), "the float64 register-stash path needs float64, hidden width 20, 4, 6 or 8 hidden layers and a Burgers problem");
   if (path == 3) REQUIRE(wide_ok(c), "the wide path needs float32, hidden width 100 and two outputs");
   if (path == 1)
     REQUIRE(fused_ok(c), "the fused path needs hidden width 20, a Burgers problem and weights that fit LDS");
   if (path == 2)
-    REQUIRE(fused_regs_ok(c), "the register-stash path needs float32, hidden width 20, 8 hidden layers and a Burgers problem");
+    REQUIRE(fused_regs_ok(c), "the register-stash path needs float32, hidden width 20, 4, 6, 8 or 10 hidden layers and a Burgers problem");
   c->path = path;
   c->sets_dirty = true;
   return 0;

@@ -20,7 +20,8 @@ inline size_t fused20d_lds_bytes(int n_hidden, int n_theta) {
 // entry e = 16 * block + 4 * i + j of a wave's block list -> flat parameter index (reference layout), -1 = padding
 void fused20d_row_index(const NetDesc& nd, int H, int* out);
 
-// one loss+gradient evaluation (pde 0: Burgers inference, 1: identification; H = 8 hidden layers); returns a hipError_t
+inline bool fused20d_depth_ok(int n_hidden) { return n_hidden == 4 || n_hidden == 6 || n_hidden == 8; }
+// one loss+gradient evaluation (pde 0: Burgers inference, 1: identification; 4, 6 or 8 hidden layers); returns a hipError_t
 int fused20d_launch_any(int pde, const NetDesc& nd, const SetDesc& sd, const double* th, const double* xs,
                         const double* ts, const double* tgt, double lbx, double lbt, double sx, double st, double nu,
                         double* part, int R, int n_wg, const int* row_index, hipStream_t stream, long long* stamps,

@@ -29,12 +29,14 @@ int fused20d_launch_any(int pde, const NetDesc& nd, const SetDesc& sd, const dou
                         const double* ts, const double* tgt, double lbx, double lbt, double sx, double st, double nu,
                         double* part, int R, int n_wg, const int* row_index, hipStream_t stream, long long* stamps,
                         hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (nd.n_hidden != 8) return (int)hipErrorInvalidValue;
-  if (pde == 1)
-    return fused20d_launch<1, 8>(nd, sd, th, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_wg, row_index, stream,
-                                 stamps, ev_start, ev_stop);
-  return fused20d_launch<0, 8>(nd, sd, th, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_wg, row_index, stream,
-                               stamps, ev_start, ev_stop);
+#define ARGS nd, sd, th, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_wg, row_index, stream, stamps, ev_start, ev_stop
+  switch (nd.n_hidden) {     // the AGPR stash holds (H - 2) x 40 registers: depths up to 8 fit the 256 of a wave
+    case 4: return pde == 1 ? fused20d_launch<1, 4>(ARGS) : fused20d_launch<0, 4>(ARGS);
+    case 6: return pde == 1 ? fused20d_launch<1, 6>(ARGS) : fused20d_launch<0, 6>(ARGS);
+    case 8: return pde == 1 ? fused20d_launch<1, 8>(ARGS) : fused20d_launch<0, 8>(ARGS);
+    default: return (int)hipErrorInvalidValue;
+  }
+#undef ARGS
 }
 
 }  // namespace pinn

@@ -131,8 +131,14 @@ constexpr int WIMG = 820;
 // instructions, so the compiler's vmcnt bookkeeping stays exact and waiting for an earlier plain load
 // does not wait for the image)
 inline size_t fused20m_image_floats(int n_hidden) { return ((size_t)(n_hidden - 1) * WIMG + 1023) / 1024 * 1024; }
+// exchange area in float4: the four [FROWS][65] tiles + the group-4 meeting point Q -- or, if larger, what the
+// epilogue parks there (25 row-sum rows of 68 floats per wave + the weight-gradient partials of (H-1) layers)
+constexpr int fused20m_xchg_v4(int n_hidden) {
+  const int tiles = (4 * FROWS + 4) * 65, epi = 25 * 68 + 4 * (n_hidden - 1) * 2 * 64;
+  return tiles > epi ? tiles : epi;
+}
 inline size_t fused20m_lds_bytes(int n_hidden) {
-  return fused20m_image_floats(n_hidden) * 4 + (size_t)(4 * FROWS + 4) * 65 * 16;
+  return fused20m_image_floats(n_hidden) * 4 + (size_t)fused20m_xchg_v4(n_hidden) * 16;
 }
 
 // Called by every kernel that writes a weight: mirrors flat parameter i into the LDS image.
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     // behind the four waves' row areas: the weight-gradient partials, [wave][layer][main|fringe][lane]
     constexpr int PSW = (H - 1) * 2 * 64;            // float4 per wave
     v4f* const psum = xb + NV * RSF;
-    static_assert(NV * RSF + 4 * PSW <= 4 * BUFV, "partials fit in the exchange area");
+    static_assert(NV * RSF + 4 * PSW <= fused20m_xchg_v4(H), "partials fit in the exchange area");
 #pragma unroll
     for (int d = 1; d < H; ++d) {
       psum[wave * PSW + ((d - 1) * 2 + 0) * 64 + lane] = dwm[d];
@@ -581,14 +587,14 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     }
     STAMP(31);
     // dW / db: the four waves' partial blocks (published above) are added up layer by layer, wave w
-    // taking layers w+1 and w+5.  b_d sits right behind W_d in the flat layout, so input-feature row
+    // taking layers w+1, w+5, ...  b_d sits right behind W_d in the flat layout, so input-feature row
     // 20 (the ones row) lands on the bias.
     lds_barrier();
     const int km = 4 * (lane >> 4), jm = lane & 15;              // main block: VGPR r -> input feature km + r
     const int kf = 4 * fkg, jf = 4 * fjg + (lane & 3);           // fringe block: VGPR r -> input feature kf + r
     const bool okf = fblk <= 13;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < (H - 1 + 3) / 4; ++half) {
       const int d1 = wave + 4 * half;
       if (d1 < H - 1) {
         float* __restrict__ dst = row + nd.off_w[1] + d1 * (FW * FW + FW);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h", "kernels_predict20.h",
+SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "fused20m_unit.hip", "fused20m_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h", "kernels_predict20.h",
            "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
@@ -32,7 +32,7 @@ class PinnNativeError(RuntimeError):
 
 
 COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
-UNITS = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])]
+UNITS = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]), ("fused20m_unit.hip", [])]
 
 
 def _build_tag():
@@ -70,8 +70,9 @@ def build(force=False, verbose=False, stamps=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not stamps and not _stale():        # another process built it while we waited
             return LIB_PATH
-        # two translation units (compiled concurrently), one shared object: k_fused20d wants its matrix results in
-        # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation
+        # three translation units (compiled concurrently), one shared object: k_fused20d wants its matrix results in
+        # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation; fused20m_unit.hip holds
+        # the float32 register-stash kernel at the depths other than 8
         common = [hipcc] + COMMON_FLAGS + (["-DPINN_STAMPS"] if stamps else [])
         with tempfile.TemporaryDirectory(prefix="pinn_build_", dir=_HERE) as tmp:
             objs, procs = [], []

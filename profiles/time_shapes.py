@@ -11,7 +11,7 @@ from oracle import init
 np.random.seed(1234)
 r = burgersutil.prep_data(os.path.join(bench.PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, 10000, noise=0.0)
 X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
-for layers in ([2] + [20] * 8 + [1], [2] + [20] * 4 + [1], [2] + [20] * 10 + [1], [2] + [32] * 4 + [1], [2] + [50] * 4 + [1],
+for layers in ([2] + [20] * 8 + [1], [2] + [20] * 4 + [1], [2] + [20] * 6 + [1], [2] + [20] * 10 + [1], [2] + [32] * 4 + [1], [2] + [50] * 4 + [1],
                [2] + [64] * 6 + [1], [2] + [100] * 4 + [1], [2] + [128] * 3 + [1]):
     for dt in ("f32", "f64"):
         eng = pinn_native.Engine(layers, lb, ub, pde="burgers", dtype=dt)

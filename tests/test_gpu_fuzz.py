@@ -126,3 +126,56 @@ def test_shape_generic_path_trains_like_the_reference_implementation():
     assert np.max(np.abs(out[0][0] - out[4][0]) / out[0][0]) < 1e-9
     assert len(out[0][1]) == len(out[4][1]) and np.max(np.abs(out[0][1] - out[4][1]) / out[0][1]) < 1e-7
     assert out[4][0][-1] < out[4][0][0]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("pde_kind", ["burgers", "burgers_ide"])
+@pytest.mark.parametrize("H", [4, 6, 10])
+@pytest.mark.parametrize("n_pts", [700, 40000])
+def test_register_stash_kernels_at_other_depths(dtype, pde_kind, H, n_pts):
+    """hp["layers"] is free-form in the reference (1d-burgers/inf_cont_burgers.py:23-43): 4x20, 6x20 and 10x20 nets run
+    on the register-stash kernels too (k_fused20m: depths 4, 6, 8, 10; k_fused20d: 4, 6, 8 -- its AGPR stash of
+    (H - 2) x 40 registers ends at 8), one tile per workgroup (700 points) and persistent multi-tile (40000 points),
+    against the oracle and bit-reproducibly; 10x20 in float64 stays on the HBM-stash kernel"""
+    import pinn_native
+    from oracle import pde
+    rs = np.random.RandomState(1000 * H + n_pts % 97)
+    layers = [2] + [20] * H + [1]
+    P = sum(a * b + b for a, b in zip(layers[:-1], layers[1:]))
+    w = 0.9 / np.sqrt(20.0) * rs.standard_normal(P)
+    pts = lambda n: np.column_stack([rs.uniform(LB[0], UB[0], n), rs.uniform(LB[1], UB[1], n)])
+    eng = pinn_native.Engine(layers, LB, UB, pde=pde_kind, dtype=dtype)
+    want_path = 2 if dtype == "f32" else (7 if H <= 8 else 1)
+    assert eng.kernel_path() == want_path, (eng.kernel_path(), want_path)
+    if pde_kind == "burgers":
+        X_f, X_u = pts(n_pts), pts(61)
+        u = rs.standard_normal((61, 1))
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(NU)
+        ref = pde.burgers_loss_grad(w, layers, LB, UB, X_f, X_u, u, NU)
+    else:
+        w = np.concatenate([w, [0.6, -4.5]])
+        X_u = pts(n_pts)
+        u = rs.standard_normal((n_pts, 1))
+        eng.set_data(X_u, u)
+        ref = pde.burgers_ide_loss_grad(w, layers, LB, UB, X_u, u)
+    eng.set_weights(w)
+    loss, grad, _ = eng.loss_grad()
+    tl, tg = (1e-11, 1e-10) if dtype == "f64" else (2e-5, 5e-5)
+    assert abs(loss - ref[0]) <= tl * abs(ref[0]), (loss, ref[0])
+    assert rel(grad, ref[1]) <= tg, rel(grad, ref[1])
+    loss2, grad2, _ = eng.loss_grad()
+    assert loss2 == loss and np.array_equal(grad, grad2)
+    eng.adam_init(0.01); la = eng.adam_run(3)                   # the packed weight image follows the optimiser
+    eng.lbfgs_begin(4, 0.8, 50, float(np.finfo(float).eps)); _, ll, done = eng.lbfgs_run(4)
+    assert np.all(np.isfinite(la)) and np.all(np.isfinite(ll)) and la[1] != la[0]
+    lw, gw, _ = eng.loss_grad()
+    eng2 = pinn_native.Engine(layers, LB, UB, pde=pde_kind, dtype=dtype)
+    eng2.set_kernel_path(1)
+    if pde_kind == "burgers":
+        eng2.set_collocation(X_f); eng2.set_data(X_u, u); eng2.set_pde_params(NU)
+    else:
+        eng2.set_data(X_u, u)
+    eng2.set_weights(eng.get_weights())
+    l1, g1, _ = eng2.loss_grad()
+    assert abs(lw - l1) <= tl * 10 * abs(l1) and rel(gw, g1) <= tg * 10
+    eng.close(); eng2.close()
