@@ -75,9 +75,17 @@ def record(request):
 
 def ensemble_accepts(errors, value):
     """Acceptance rule for a final error of a roundoff-chaotic schedule, given the reference's own ensemble `errors`
-    (final errors of reference runs whose initial weights differ by a few ulp): the value may be no further from
-    the ensemble's median than the ensemble's own most distant member.  -> (ok, median, radius)"""
+    (final errors of >= 25 reference runs whose initial weights differ by a few ulp): the value must lie INSIDE the
+    range the reference itself produced, [min, max] -- no margin.  -> (ok, min, max)
+    (Rounds 1-2 accepted median +- the most distant member, i.e. values outside the observed range.)"""
     e = np.sort(np.asarray(errors, dtype=np.float64))
-    med = float(np.median(e))
-    radius = float(np.max(np.abs(e - med)))
-    return abs(value - med) <= radius, med, radius
+    assert e.size >= 25, "the acceptance range is only meaningful over a sizeable ensemble (make_band.py)"
+    return bool(e[0] <= value <= e[-1]), float(e[0]), float(e[-1])
+
+
+def same_distribution_p(a, b):
+    """two-sided Mann-Whitney U (rank) test that two samples of final errors come from one distribution -> p-value.
+    What is asserted is p >= 1e-3: a correct implementation fails one run in a thousand, a biased one (all its errors
+    below / above the reference's) gives p ~ 1e-9 at 25 + 25 members."""
+    from scipy.stats import mannwhitneyu
+    return float(mannwhitneyu(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), alternative="two-sided").pvalue)

@@ -83,6 +83,8 @@ def band(name, hp, fields_file=None, ks=K_ULP, eps=EPS):
     rec["band"] = [min(errs), max(errs)]
     rec["reference_final_error"] = rec["runs"]["0"]["final_error"]
     rec["runs"] = {str(k): rec["runs"][str(k)] for k in ks}
+    if os.path.exists(path) and "note" in json.load(open(path)):
+        rec["note"] = json.load(open(path))["note"]          # provenance of earlier members (thread counts)
     with open(path, "w") as f:
         json.dump(rec, f, indent=1)
     if fields_file:

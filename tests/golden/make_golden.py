@@ -17,6 +17,7 @@ What each fixture pins, and from which reference code:
   burgers_lbfgs.npz      custom_lbfgs.lbfgs driven by the PINN closure (utils/custom_lbfgs.py:39-236)
   lbfgs_kat.json         custom_lbfgs.lbfgs on a 6-D analytic function
   burgers_default_run.json  stdout of the unmodified script with default hp
+  burgers_default_trace.npz the same run, every epoch's / iteration's loss at full precision (Logger wrapped from outside)
   schrodinger_eval.npz   SchrodingerInformedNN.loss at the canonical init (compat x0 broadcast)
   logger_bytes.json      utils/logger.py output format
   burgers_ide_eval.npz   identification variant (1d-burgers/ide_cont_burgers.py:47-172): the file does not
@@ -231,6 +232,34 @@ def gen_default_run():
     with open(os.path.join(HERE, "burgers_default_run.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print("default run: final error %.6e" % rec["final_error"])
+
+
+def gen_default_trace():
+    """the default run again with the reference's Logger.log_train_epoch wrapped (from outside; the script and utils/
+    are untouched): EVERY epoch's / iteration's loss at full precision instead of the 4 printed digits of every 10th --
+    what `first L-BFGS iteration whose loss departs by more than 1e-6` is measured against"""
+    sys.path.insert(1, os.path.join(REF, "utils"))
+    import logger as ref_logger
+    rows = []
+    orig = ref_logger.Logger.log_train_epoch
+
+    def spy(self, epoch, loss, custom="", is_iter=False):
+        rows.append((int(epoch), float(loss), bool(is_iter)))
+        return orig(self, epoch, loss, custom, is_iter)
+    ref_logger.Logger.log_train_epoch = spy
+    try:
+        hp = burgers_hp(tf_epochs=100, nt_epochs=200)
+        g, out = run_reference_script("1d-burgers/inf_cont_burgers.py", hp)
+    finally:
+        ref_logger.Logger.log_train_epoch = orig
+    adam = [r for r in rows if not r[2]]
+    lb = [r for r in rows if r[2]]
+    assert [r[0] for r in adam] == list(range(100)), len(adam)
+    np.savez_compressed(os.path.join(HERE, "burgers_default_trace.npz"),
+                        adam_losses=np.array([r[1] for r in adam]), lbfgs_iters=np.array([r[0] for r in lb]),
+                        lbfgs_losses=np.array([r[1] for r in lb]), final_error=float(g["error"]()),
+                        hp=json.dumps(hp))
+    print("default trace: %d Adam + %d L-BFGS losses, final error %.6e" % (len(adam), len(lb), float(g["error"]())))
 
 
 def gen_schrodinger_eval():
@@ -584,6 +613,8 @@ def main():
         gen_schrodinger_run()
     if "default" in which:
         gen_default_run()
+    if "default_trace" in which or not sys.argv[1:]:
+        gen_default_trace()
     if "full_runs" in which:
         gen_full_runs()
     if "disc" in which:

@@ -10,11 +10,20 @@ number read from a fixture the reference produced:
      after 50 / 100 further L-BFGS iterations, the GPU-trained weights, the field u(X_star) on the 25600-point grid
      and the error agree with the reference's to the tolerances in PREFIX_TOL (the 1e-3 of north_star holds
      there, with margin);
-  2. the full default schedule (100 Adam + 200 L-BFGS) in float64 AND float32 ends inside the reference's own
-     ulp-perturbation ensemble (rule: conftest.ensemble_accepts), and the float64 field is compared with the
-     reference's trained field burgers_default_run_w_final.npy -> predict(X_star);
+  2. the full default schedule (100 Adam + 200 L-BFGS) ends INSIDE [min, max] of the reference's own 25-member
+     perturbation ensemble -- float64 against the (1 + k 2^-52) ensemble, float32 against the (1 + k 2^-23) one (a
+     float32 implementation perturbs by that much at every step) -- and the trained field is as close to the
+     reference's as the reference's own perturbed runs are;
+  2b. the GPU engines run under the SAME 25 perturbations: their error distributions must pass a rank test
+     (Mann-Whitney) against the reference's -- one sample could sit inside a wide range by luck, 25 cannot;
   3. BASELINE configs[0] (Adam x 2000, lr 0.03, reference value 4.3073e-01): float64 log prefix against the
-     reference's printed log until its first loss spike, final error inside that configuration's ensemble.
+     reference's printed log until its first loss spike, and the distribution of the GPU's 25 final errors against the
+     reference's 25 (rank test) instead of a radius that accepted anything up to 1.0;
+  4. for both L-BFGS kernels (mode 0 = the reference's operation order, mode 1 = compact form): the first iteration
+     whose float64 loss departs from the reference's full-precision trace (burgers_default_trace.npz) by > 1e-6.
+north_star's literal "final L2 error within 1e-3 of reference" is recorded per dtype (`err_absdiff_vs_k0`) and is NOT
+met at the end of the full schedule (f64 2.7e-3, f32 2.3e-2): two runs of the reference itself differ by more (8 vs 4
+torch threads: 0.26564 vs 0.26739) -- README.md states it.
 """
 import json
 import os
@@ -23,7 +32,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import PKG, ensemble_accepts, golden
+from conftest import PKG, ensemble_accepts, golden, same_distribution_p
 
 pytestmark = pytest.mark.gpu
 
@@ -70,17 +79,27 @@ def test_f64_trained_field_tracks_reference_on_schedule_prefixes(burgers_sets, m
     assert dw < tw and du < tu and de < te, (tag, dw, du, de)
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_default_schedule_final_error_inside_reference_ensemble(burgers_sets, monkeypatch, record, dtype):
-    b = json.load(open(golden("burgers_band.json")))
-    errors = [v["final_error"] for v in b["runs"].values()]
-    pinn = _run(dict(b["hp"], dtype=dtype), monkeypatch)
+def _band(dtype):
+    return json.load(open(golden("burgers_band.json" if dtype == "f64" else "burgers_band_eps32.json")))
+
+
+def _final_error(pinn, burgers_sets):
     X_star, u_star = _grid(burgers_sets)
     u = pinn.predict(X_star)[0][:, 0]
-    err = float(np.linalg.norm(u_star[:, 0] - u, 2) / np.linalg.norm(u_star[:, 0], 2))
-    ok, med, radius = ensemble_accepts(errors, err)
+    return float(np.linalg.norm(u_star[:, 0] - u, 2) / np.linalg.norm(u_star[:, 0], 2)), u
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_default_schedule_final_error_inside_reference_ensemble(burgers_sets, monkeypatch, record, dtype):
+    b = _band(dtype)
+    errors = [v["final_error"] for v in b["runs"].values()]
+    pinn = _run(dict(b["hp"], dtype=dtype), monkeypatch)
+    err, u = _final_error(pinn, burgers_sets)
+    assert abs(pinn.error_l2(*_grid(burgers_sets)) - err) <= 1e-13 * err          # the device-side metric agrees
+    ok, lo, hi = ensemble_accepts(errors, err)
     # the reference's own trained field (k = 0 run): how far two members of the ensemble are apart, for the record
     from oracle import mlp
+    X_star, _ = _grid(burgers_sets)
     w_ref = np.load(golden("burgers_default_run_w_final.npy"))
     lb, ub = np.array([-1.0, 0.0]), np.array([1.0, 0.99])
     u_ref = mlp.forward_value(mlp.unpack(w_ref, b["hp"]["layers"]), X_star, lb, ub)[:, 0]
@@ -88,10 +107,33 @@ def test_default_schedule_final_error_inside_reference_ensemble(burgers_sets, mo
     assert np.max(np.abs(u_ref - f["u_k0_full"])) < 1e-12          # the two fixtures describe the same run
     spread = max(float(np.sqrt(np.mean((f[k] - f["u_k+0"]) ** 2))) for k in f.files if k.startswith("u_k") and k not in ("u_k0_full", "u_k+0"))
     rms = float(np.sqrt(np.mean((u[::5] - f["u_k+0"]) ** 2)))
-    record(dtype=dtype, err_gpu=err, ens_median=med, ens_radius=radius, ens_min=min(errors), ens_max=max(errors),
-           field_rms_vs_ref=rms, ensemble_field_rms_spread=spread, reference_error=b["reference_final_error"])
-    assert ok, (dtype, err, med, radius, sorted(errors))
+    ref0 = json.load(open(golden("burgers_band.json")))["reference_final_error"]
+    record(dtype=dtype, err_gpu=err, ens_min=lo, ens_max=hi, members=len(errors), field_rms_vs_ref=rms,
+           ensemble_field_rms_spread=spread, reference_error=ref0, err_absdiff_vs_k0=abs(err - ref0),
+           within_1e_3_of_reference=bool(abs(err - ref0) <= 1e-3))
+    assert ok, (dtype, err, lo, hi)
     assert rms <= 1.5 * spread, (rms, spread)      # as close to the reference's field as its own perturbed runs are
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_gpu_ensemble_ranks_like_the_reference_ensemble(burgers_sets, monkeypatch, record, dtype):
+    """the engine under the same 25 perturbations of the initial kernels as the reference (hp["init_scale"] = 1 + k eps):
+    its final errors and the reference's must be samples of one distribution (rank test), and every GPU member must
+    stay inside a range no wider than the reference's own, stretched by its own width on either side (a blow-up or a
+    collapse of a single member is a failure too)"""
+    b = _band(dtype)
+    ref = [b["runs"][str(k)]["final_error"] for k in b["k_ulp"]]
+    mine = []
+    for k in b["k_ulp"]:
+        pinn = _run(dict(b["hp"], dtype=dtype, init_scale=1.0 + k * b["eps"]), monkeypatch)
+        mine.append(_final_error(pinn, burgers_sets)[0])
+    p = same_distribution_p(mine, ref)
+    lo, hi = min(ref), max(ref)
+    record(dtype=dtype, p_mannwhitney=p, gpu_min=min(mine), gpu_median=float(np.median(mine)), gpu_max=max(mine),
+           ref_min=lo, ref_median=float(np.median(ref)), ref_max=hi, members=len(mine),
+           gpu_inside_ref_range=int(sum(lo <= e <= hi for e in mine)))
+    assert p >= 1e-3, (dtype, p, sorted(mine), sorted(ref))
+    assert lo - (hi - lo) <= min(mine) and max(mine) <= hi + (hi - lo), (sorted(mine), lo, hi)
 
 
 def test_cfg1_adam2000_log_prefix_and_final_error(burgers_sets, monkeypatch, capsys, record):
@@ -99,7 +141,7 @@ def test_cfg1_adam2000_log_prefix_and_final_error(burgers_sets, monkeypatch, cap
     tf_epochs = 2000, nt_epochs = 0)."""
     import re
     b = json.load(open(golden("burgers_cfg1_band.json")))
-    errors = [v["final_error"] for v in b["runs"].values()]
+    errors = [b["runs"][str(k)]["final_error"] for k in b["k_ulp"]]
     pinn = _run(dict(b["hp"], dtype="f64"), monkeypatch)
     out = capsys.readouterr().out
     line = re.compile(r"^tf_epoch =\s+(\d+)\s+elapsed = \S+ \(\S+\)  loss = (\S+)  ")
@@ -109,11 +151,53 @@ def test_cfg1_adam2000_log_prefix_and_final_error(burgers_sets, monkeypatch, cap
     # the two logs must agree (4 printed digits) up to the reference's first loss spike, and for >= 100 epochs
     first_bad = next((ep for ep in sorted(ref) if abs(mine[ep] - ref[ep]) > 2e-4 * ref[ep]), 2000)
     spike = next((ep for ep, nxt in zip(sorted(ref), sorted(ref)[1:]) if ep >= 100 and ref[nxt] > 1.5 * ref[ep]), 2000)
-    X_star, u_star = _grid(burgers_sets)
-    u = pinn.predict(X_star)[0][:, 0]
-    err = float(np.linalg.norm(u_star[:, 0] - u, 2) / np.linalg.norm(u_star[:, 0], 2))
-    ok, med, radius = ensemble_accepts(errors, err)
-    record(first_disagreeing_epoch=first_bad, reference_first_spike_epoch=spike, err_gpu=err, ens_median=med,
-           ens_radius=radius, reference_error=b["reference_final_error"])
+    err = _final_error(pinn, burgers_sets)[0]
+    ok, lo, hi = ensemble_accepts(errors, err)
+    # distribution overlap: the engine under the reference's 25 perturbations (2000 Adam steps each: 0.1 s of GPU time)
+    gpu = [err]
+    for k in b["k_ulp"][1:]:
+        gpu.append(_final_error(_run(dict(b["hp"], dtype="f64", init_scale=1.0 + k * b.get("eps", 2.0 ** -52)), monkeypatch),
+                                burgers_sets)[0])
+    capsys.readouterr()
+    p = same_distribution_p(gpu, errors)
+    record(first_disagreeing_epoch=first_bad, reference_first_spike_epoch=spike, err_gpu=err, ens_min=lo, ens_max=hi,
+           reference_error=b["reference_final_error"], p_mannwhitney=p, gpu_min=min(gpu),
+           gpu_median=float(np.median(gpu)), gpu_max=max(gpu), ref_median=float(np.median(errors)))
     assert first_bad >= min(spike, 100), (first_bad, spike)
-    assert ok, (err, med, radius, sorted(errors))
+    assert ok, (err, lo, hi)
+    assert p >= 1e-3, (p, sorted(gpu), sorted(errors))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_first_lbfgs_iteration_departing_from_the_reference_trace(burgers_sets, record, mode):
+    """the default schedule on the engine (float64) against the reference's full-precision trace of the same run
+    (tests/golden/burgers_default_trace.npz: the reference script with Logger.log_train_epoch wrapped): every Adam
+    loss to 1e-10, then the first L-BFGS iteration whose loss is off by more than 1e-6 (relative), for the kernel that
+    follows the reference's operation order (mode 0) and for the compact form (mode 1, the default).  The schedule is
+    roundoff-chaotic (a 1-ulp change of the initial weights moves the final error by 4e-2), so a departure is expected
+    -- the assertion is that it comes late"""
+    from pinn_native import Engine
+    t = np.load(golden("burgers_default_trace.npz"))
+    g = np.load(golden("burgers_eval.npz"))
+    r = burgers_sets(100, 10000)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    eng = Engine([2] + [20] * 8 + [1], lb, ub, pde="burgers", dtype="f64")
+    eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(0.01 / np.pi)
+    eng.set_weights(g["w0"])
+    eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+    la = eng.adam_run(100)
+    adam_dev = float(np.max(np.abs(la - t["adam_losses"]) / t["adam_losses"]))
+    eng.lbfgs_set_mode(mode)
+    eng.lbfgs_begin(200, 0.8, 50, float(np.finfo(float).eps))
+    its, ll, done = eng.lbfgs_run(200)
+    assert done == 1 and np.array_equal(its, t["lbfgs_iters"])
+    dev = np.abs(ll - t["lbfgs_losses"]) / t["lbfgs_losses"]
+    first = int(its[np.argmax(dev > 1e-6)]) if np.any(dev > 1e-6) else 0
+    first9 = int(its[np.argmax(dev > 1e-9)]) if np.any(dev > 1e-9) else 0
+    err = eng.error_l2(*_grid(burgers_sets))
+    record(mode=mode, adam_loss_dev=adam_dev, first_iter_off_by_1e_9=first9, first_iter_off_by_1e_6=first,
+           dev_at_50=float(dev[49]), dev_at_100=float(dev[99]), dev_at_150=float(dev[149]), dev_last=float(dev[-1]),
+           final_error=err, reference_final_error=float(t["final_error"]))
+    assert adam_dev < 1e-10
+    assert first == 0 or first >= 60, (mode, first)
+    eng.close()
