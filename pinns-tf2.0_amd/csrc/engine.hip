@@ -431,11 +431,13 @@ template <typename real, int NT, bool WLDS>
 static int t16_launch_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int chunk, void* O, int base, int pts,
                           real lbx, real lbt, real sx, real st) {
   static unsigned long long attr = 0;
-  const size_t lds = t16_fwd_lds<NT>(sizeof(real), WLDS);
+  // eight waves per workgroup where LDS admits one workgroup per CU only (float64, widths above 64): two waves per SIMD
+  constexpr int NWV = (sizeof(real) == 8 && NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
+  const size_t lds = t16_fwd_lds<NT>(sizeof(real), WLDS, NWV);
   if (first_call_on_device(attr))
-    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT, WLDS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
-  hipLaunchKernelGGL((k_t16_fwd<real, NT, WLDS>), dim3(t16_wgs(c, pts)), dim3(256), lds, c->stream, c->nd,
+  hipLaunchKernelGGL((k_t16_fwd<real, NT, WLDS, NWV>), dim3(t16_wgs(c, pts)), dim3(64 * NWV), lds, c->stream, c->nd,
                      (const real*)c->theta_r, (const real*)xs, (const real*)ts, base, n_pad, chunk,
                      pts / 16, lbx, lbt, sx, st, (vec4<real>*)c->S, (vec4<real>*)O);
   return 0;
@@ -443,15 +445,16 @@ static int t16_launch_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad
 template <typename real, int NT, int PDE, bool WLDS>
 static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
   static unsigned long long attr = 0;
+  constexpr int NWV = (sizeof(real) == 8 && NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
   const size_t lds = t16_bwd_lds<NT>(sizeof(real), WLDS);
   if (first_call_on_device(attr))
-    HIPCHK(hipFuncSetAttribute((const void*)k_t16_bwd<real, NT, PDE, WLDS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_bwd<real, NT, PDE, WLDS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds));
   // one partial row per workgroup: never launch more workgroups than the rows sized for a full chunk (t16_wgs is
   // not monotone in pts: a short last chunk may prefer three workgroups per CU where the full chunk took two)
   const int rows_cap = t16_wgs(c, c->chunk);
   const int wgs = t16_wgs(c, pts) < rows_cap ? t16_wgs(c, pts) : rows_cap;
-  hipLaunchKernelGGL((k_t16_bwd<real, NT, PDE, WLDS>), dim3(wgs), dim3(256), lds, c->stream, c->nd, c->sd,
+  hipLaunchKernelGGL((k_t16_bwd<real, NT, PDE, WLDS, NWV>), dim3(wgs), dim3(64 * NWV), lds, c->stream, c->nd, c->sd,
                      (const real*)c->theta_r, (const real*)c->xs, (const real*)c->ts, (const real*)c->tgt, base,
                      c->sd.n_pad, c->chunk, pts / 16, lbx, lbt, sx, st, (real)c->nu, (const vec4<real>*)c->S,
                      (const vec4<real>*)c->O, (real*)c->part, c->R, accumulate);

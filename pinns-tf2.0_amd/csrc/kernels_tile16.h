@@ -20,8 +20,51 @@
 // Math: SURVEY.md Appendix A (channels_of / preact_adjoint / point_seeds of kernels_generic.h).
 #pragma once
 #include "kernels_disc.h"
+#include "kernels_fused20d.h"
 
 namespace pinn {
+
+// tanh of the MFMA sweeps.  float64: the library tanh() is several hundred instructions with branches -- at width 100
+// a lane evaluates 8 of them per layer behind 12.8 k cycles of matrix instructions, on a SIMD that holds one wave, so
+// they were a third of the forward sweep (cfg 4 float64: 286 us -> profiles/r03_time_cfg4.txt); tanh_d is the
+// exp + Newton-quotient form of k_fused20d (relative error < 1e-16 before the final rounding).  float32 keeps tanhf.
+// Ablation builds (profiles/ablate_t16.py, -DT16_ABL=n): one ingredient of the two sweeps compiled out at a time -- wrong
+// results by construction, only the kernel times are read.  0 / undefined = the product kernels.
+//   1 no stash traffic (forward does not store S, reverse reads one cached line instead)   2 no matrix instructions
+//   3 reverse: weight-gradient tiles are not added into the partial row (no read-modify-write)   4 tanh -> multiply
+#ifndef T16_ABL
+#define T16_ABL 0
+#endif
+#ifndef T16_WIDE_WAVES
+#define T16_WIDE_WAVES 8       // waves per workgroup of the float64 sweeps above width 64 (4 = the round-2 kernels)
+#endif
+#ifndef T16_DEPTH
+#define T16_DEPTH 2            // chunks of four k-steps of L2-resident weights in flight ahead of the one in use
+#endif
+template <typename real> __device__ __forceinline__ real tanh_mm(real z);
+template <> __device__ __forceinline__ float tanh_mm<float>(float z) { return tanhf(z); }
+template <> __device__ __forceinline__ double tanh_mm<double>(double z) {
+#if T16_ABL == 4
+  return z * 0.125;
+#endif
+  return tanh_d(z);
+}
+template <typename real, typename acc_t>
+__device__ __forceinline__ acc_t t16_mfma(real a, real b, acc_t c) {
+#if T16_ABL == 2
+  c[0] += a * b;
+  return c;
+#else
+  return FusedTraits<real>::mfma(a, b, c);
+#endif
+}
+#if T16_ABL == 1
+#define T16_SIDX(expr) ((size_t)0 * (expr) + (threadIdx.x & 15))
+#define T16_SSTORE(dst, val) do { } while (0)
+#else
+#define T16_SIDX(expr) (expr)
+#define T16_SSTORE(dst, val) (dst) = (val)
+#endif
 
 template <int NT> struct T16Geo {
   static constexpr int WP = 16 * NT;
@@ -31,8 +74,8 @@ template <int NT> struct T16Geo {
   static constexpr int TLD = WP + 4;           // weights [k][j] read as A[m = k][4s+g = j]
   static constexpr int NPRE = WP * WP / 256;
 };
-template <int NT> inline size_t t16_fwd_lds(size_t rs, bool wlds) {
-  return (size_t)(2 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::WLD : 0) + 8 * 2 * 16 * 4) * rs;
+template <int NT> inline size_t t16_fwd_lds(size_t rs, bool wlds, int nwv = 4) {
+  return (size_t)(2 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::WLD : 0) + 2 * nwv * 2 * 16 * 4) * rs;
 }
 template <int NT> inline size_t t16_bwd_lds(size_t rs, bool wlds) {
   return (size_t)(2 * T16Geo<NT>::TILE * 4 + (wlds ? T16Geo<NT>::WP * T16Geo<NT>::TLD : 0) + 2 * 16 * 4 + 32) * rs;
@@ -47,8 +90,13 @@ __device__ __forceinline__ real sum16(real v) {        // sum over the 16 lanes 
 // ---------------------------------------------------------------------------------------------------------
 // forward sweep over points [base, base + 16 n_groups): fills S and O exactly as k_forward does
 // ---------------------------------------------------------------------------------------------------------
-template <typename real, int NT, bool WLDS>
-__global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restrict__ th,
+// NWV = waves per workgroup: 4 (one per SIMD), or 8 for the widths whose two exchange tiles leave room for ONE
+// workgroup per CU (float64 above width 64): the group's tiles are then dealt to eight waves, two per SIMD, and one
+// wave's matrix instructions run under the other's loads, address arithmetic and tanh chain.  (SQ counters of the
+// 4-wave float64 width-100 sweeps, profiles/r03_pmc_cfg4_f64.txt: matrix pipe busy 39 % / 28 % of the wave cycles,
+// the rest issue of other instructions and s_waitcnt -- nothing overlapped with one wave per SIMD.)
+template <typename real, int NT, bool WLDS, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_t16_fwd(NetDesc nd, const real* __restrict__ th,
                                                  const real* __restrict__ xs, const real* __restrict__ ts, int base,
                                                  int n_pad, int s_pad, int n_groups, real lbx, real lbt, real sx,
                                                  real st, vec4<real>* __restrict__ S, vec4<real>* __restrict__ O) {
@@ -61,7 +109,12 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
   V4* const T0 = reinterpret_cast<V4*>(t16_smem);
   V4* const T1 = T0 + GEO::TILE;
   real* const wb = reinterpret_cast<real*>(T1 + GEO::TILE);      // [WP][WLD] (WLDS only; else weights come from L2)
-  real* const red = wb + (WLDS ? WP * WLD : 0);                   // [8][2][16][4] output-layer partials
+  real* const red = wb + (WLDS ? WP * WLD : 0);                   // [2 NWV][2][16][4] output-layer partials
+  static_assert(NWV == 4 || !WLDS, "the LDS weight staging is written for 256 threads");
+  constexpr int RP = 4 * NWV;                                     // feature rows per elementwise pass (threads / 16)
+  constexpr int NI = WP / RP;                                     // passes over the padded width
+  constexpr int KS = 2 * NWV;                                     // k-slices of the output layer (threads / 32)
+  constexpr int NKO = WP / KS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
   const int m = lane & 15, g = lane >> 4;
@@ -71,17 +124,17 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
   real pre[GEO::NPRE];                        // (dead when !WLDS)
   if constexpr (WLDS) { if (H > 1) wt_load<real, NT, WP>(pre, th + nd.off_w[1], W, W, W, tid); }
   // parameters that every group reuses: dense 0 of this thread's features, the output layer's k-slice
-  real p0x[NT], p0t[NT], p0b[NT], pout[2 * NT];
+  real p0x[NI], p0t[NI], p0b[NI], pout[NKO];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) {
-    const int j = (tid >> 4) + 16 * i;
+  for (int i = 0; i < NI; ++i) {
+    const int j = (tid >> 4) + RP * i;
     p0x[i] = j < W ? th[nd.off_w[0] + j] : real(0);
     p0t[i] = j < W ? th[nd.off_w[0] + W + j] : real(0);
     p0b[i] = j < W ? th[nd.off_b[0] + j] : real(0);
   }
 #pragma unroll
-  for (int i = 0; i < 2 * NT; ++i) {
-    const int k = (tid >> 5) + 8 * i, o = (tid >> 4) & 1;
+  for (int i = 0; i < NKO; ++i) {
+    const int k = (tid >> 5) + KS * i, o = (tid >> 4) & 1;
     pout[i] = (k < W && o < NO) ? th[nd.off_w[H] + k * NO + o] : real(0);
   }
 
@@ -91,13 +144,13 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
       const real x = xs[base + lp0 + pe], t = ts[base + lp0 + pe];
       const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        const int j = (tid >> 4) + 16 * i;
+      for (int i = 0; i < NI; ++i) {
+        const int j = (tid >> 4) + RP * i;
         V4 s{0, 0, 0, 0}, c{0, 0, 0, 0};
         if (j < W) {
           const real w0 = p0x[i], w1 = p0t[i], b0 = p0b[i];
-          s = V4{tanh_r(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
-          S[(size_t)j * s_pad + lp0 + pe] = s;
+          s = V4{tanh_mm(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
+          T16_SSTORE(S[(size_t)j * s_pad + lp0 + pe], s);
           real d1, d2;
           c = channels_of(s, d1, d2);
         }
@@ -116,7 +169,12 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
       }
       const real* __restrict__ bl = th + nd.off_b[l];
       const real* __restrict__ Wl = th + nd.off_w[l];
-      for (int ct = wave; ct < NT; ct += 4) {
+      for (int ct = wave; ct < NT; ct += NWV) {
+        if (16 * ct >= W) {                                       // tile entirely in the padding (wave-uniform): zeros
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Tout[(16 * ct + TR::out_row(lane, r)) * PD + m] = V4{0, 0, 0, 0};
+          continue;
+        }
         real bj[4];                                               // biases of this lane's four features (in flight
 #pragma unroll                                                    //  under the MFMAs)
         for (int r = 0; r < 4; ++r) {
@@ -131,35 +189,41 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
             const int k = 4 * ks + g;
             const real a = wb[k * WLD + ja];
             const V4 b = Tin[k * PD + m];                         // B[k][n = point m]
-            a0 = TR::mfma(a, b.x, a0);
-            a1 = TR::mfma(a, b.y, a1);
-            a2 = TR::mfma(a, b.z, a2);
-            a3 = TR::mfma(a, b.w, a3);
+            a0 = t16_mfma<real, acc_t>(a, b.x, a0);
+            a1 = t16_mfma<real, acc_t>(a, b.y, a1);
+            a2 = t16_mfma<real, acc_t>(a, b.z, a2);
+            a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
         } else {
           // weights straight from L2: the A operands of a chunk of four k-steps are fetched one chunk ahead, so their
           // latency (several hundred cycles) hides under the 16 matrix instructions of the chunk in flight instead
           // of stalling every chunk.  A last partial chunk runs on zero weights and the zero rows k >= W of the tile.
           const int nchunks = (ksteps + 3) >> 2;
-          real wc[4], wn[4];
+          // T16_DEPTH chunks in flight: an L2 hit costs ~1.5 k cycles here, one chunk of float64 matrix instructions
+          // lasts 1 k (ablation, profiles/r03_ablate_t16_f64.txt: with one chunk ahead every chunk stalled)
+          real wq[T16_DEPTH + 1][4];
+          auto fetch = [&](int c, real (&dst)[4]) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int k = 4 * u + g; wc[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0); }
+            for (int u = 0; u < 4; ++u) { const int k = 4 * (4 * c + u) + g; dst[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0); }
+          };
+#pragma unroll
+          for (int q = 0; q < T16_DEPTH; ++q) fetch(q, wq[q]);
           for (int c = 0; c < nchunks; ++c) {
+            fetch(c + T16_DEPTH, wq[T16_DEPTH]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const int k = 4 * (4 * (c + 1) + u) + g;
-              wn[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+              if (4 * c + u >= ksteps) break;                      // last chunk: only the k-steps that exist (uniform)
               const V4 b = Tin[(4 * (4 * c + u) + g) * PD + m];
-              a0 = TR::mfma(wc[u], b.x, a0);
-              a1 = TR::mfma(wc[u], b.y, a1);
-              a2 = TR::mfma(wc[u], b.z, a2);
-              a3 = TR::mfma(wc[u], b.w, a3);
+              a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
+              a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
+              a2 = t16_mfma<real, acc_t>(wq[0][u], b.z, a2);
+              a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wc[u] = wn[u];
+            for (int q = 0; q < T16_DEPTH; ++q) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
+            }
           }
         }
 #pragma unroll
@@ -167,8 +231,8 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
           const int j = 16 * ct + TR::out_row(lane, r);           // feature; the point is m
           V4 c{0, 0, 0, 0};
           if (j < W) {
-            const V4 s{tanh_r(a0[r] + bj[r]), a1[r], a2[r], a3[r]};
-            S[((size_t)l * W + j) * s_pad + lp0 + m] = s;
+            const V4 s{tanh_mm(a0[r] + bj[r]), a1[r], a2[r], a3[r]};
+            T16_SSTORE(S[((size_t)l * W + j) * s_pad + lp0 + m], s);
             real d1, d2;
             c = channels_of(s, d1, d2);
           }
@@ -178,12 +242,12 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
       V4* tmp = Tin; Tin = Tout; Tout = tmp;
     }
     __syncthreads();
-    {  // linear output layer: thread = (k-slice ks8, output o, point pe); 8 slices summed through LDS
+    {  // linear output layer: thread = (k-slice ks8, output o, point pe); the slices are summed through LDS
       const int o = (tid >> 4) & 1, ks8 = tid >> 5;
       V4 acc{0, 0, 0, 0};
 #pragma unroll
-      for (int i = 0; i < 2 * NT; ++i) {
-        const int k = ks8 + 8 * i;                // pout is zero beyond the width / the outputs
+      for (int i = 0; i < NKO; ++i) {
+        const int k = ks8 + KS * i;               // pout is zero beyond the width / the outputs
         const V4 b = Tin[k * PD + pe];
         const real w = pout[i];
         acc.x += b.x * w; acc.y += b.y * w; acc.z += b.z * w; acc.w += b.w * w;
@@ -193,7 +257,7 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
       if (ks8 == 0 && o < NO) {
         V4 tot = reinterpret_cast<V4*>(red)[(0 * 2 + o) * 16 + pe];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) {
+        for (int q = 1; q < KS; ++q) {
           const V4 v = reinterpret_cast<V4*>(red)[(q * 2 + o) * 16 + pe];
           tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
         }
@@ -210,8 +274,8 @@ __global__ __launch_bounds__(256) void k_t16_fwd(NetDesc nd, const real* __restr
 // all weight gradients added into one partial row per workgroup (zeroed here unless `accumulate`).
 // WLDS: the layer's weight matrix is staged in LDS for the adjoint GEMM (else read from global / L2).
 // ---------------------------------------------------------------------------------------------------------
-template <typename real, int NT, int PDE, bool WLDS>
-__global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const real* __restrict__ th,
+template <typename real, int NT, int PDE, bool WLDS, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, const real* __restrict__ th,
                                                  const real* __restrict__ xs, const real* __restrict__ ts,
                                                  const real* __restrict__ tgt, int base, int n_pad, int s_pad,
                                                  int n_groups, real lbx, real lbt, real sx, real st, real nu,
@@ -231,6 +295,8 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
   real* const wt = reinterpret_cast<real*>(TB + GEO::TILE);       // [WP][TLD] (WLDS only)
   V4* const seeds = reinterpret_cast<V4*>(wt + (WLDS ? WP * TLD : 0));   // [2][16]
   real* const hxy = reinterpret_cast<real*>(seeds + 32);          // [2][16] normalised inputs
+  static_assert(NWV == 4 || !WLDS, "the LDS weight staging is written for 256 threads");
+  constexpr int RP = 4 * NWV, THREADS = 64 * NWV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int W = nd.width, H = nd.n_hidden, NO = nd.n_out;
   const int m = lane & 15, g = lane >> 4, pe = tid & 15;
@@ -240,7 +306,7 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
   if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp_r(th[nd.n_net + 1]); }
 
   if (!accumulate) {
-    for (int i = tid; i < R; i += 256) row[i] = real(0);
+    for (int i = tid; i < R; i += THREADS) row[i] = real(0);
     __syncthreads();                          // (global stores of one workgroup, read back by the same workgroup)
   }
   real l_acc[3] = {0, 0, 0}, dl_acc[2] = {0, 0}, gb_acc[2] = {0, 0};   // threads 0..15: one point each
@@ -268,11 +334,11 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
     {  // dense H (linear): z_bar = seeds.  Items (feature j, point pe): adjoint of layer H-1's pre-activations,
        // gradient of the output weights (sum over the 16 points = the 16 lanes of a DPP row), inputs of layer H-1
       const V4 s0 = seeds[pe], s1 = seeds[16 + pe];
-      for (int j = tid >> 4; j < WP; j += 16) {
+      for (int j = tid >> 4; j < WP; j += RP) {
         V4 zb{0, 0, 0, 0};
         real gw0 = 0, gw1 = 0;
         if (j < W) {
-          const V4 s = S[((size_t)(H - 1) * W + j) * s_pad + lp0 + pe];
+          const V4 s = S[T16_SIDX(((size_t)(H - 1) * W + j) * s_pad + lp0 + pe)];
           real d1, d2;
           const V4 in = channels_of(s, d1, d2);
           const real w0 = th[nd.off_w[H] + j * NO], w1 = NO > 1 ? th[nd.off_w[H] + j * NO + 1] : real(0);
@@ -292,7 +358,7 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
           V4 c{0, 0, 0, 0};
           if (j < W) {
             real d1, d2;
-            c = channels_of(S[((size_t)(H - 2) * W + j) * s_pad + lp0 + pe], d1, d2);
+            c = channels_of(S[T16_SIDX(((size_t)(H - 2) * W + j) * s_pad + lp0 + pe)], d1, d2);
           }
           TI[j * PD + pe] = c;
         }
@@ -306,29 +372,37 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
         wt_load<real, NT, WP>(pre, th + nd.off_w[dn], W, W, W, tid);
       }
       // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j
-      for (int tau = wave; tau < NT * NT; tau += 4) {
-        const int rt = tau / NT, ct = tau - rt * NT;
-        if (16 * rt >= W || 16 * ct >= W) continue;               // wave-uniform: tile entirely in the padding
+      const int ntl = (W + 15) >> 4;                              // live tiles per side: the others are padding
+      for (int tau = wave; tau < ntl * ntl; tau += NWV) {
+        const int rt = tau / ntl, ct = tau - rt * ntl;
         const int j = 16 * ct + m;
         real old[4];                                              // the row entries to update: fetched under the MFMAs
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * rt + TR::out_row(lane, r);
+#if T16_ABL == 3
+          old[r] = real(0);
+#else
           old[r] = (k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
+#endif
         }
         acc_t acc = {0, 0, 0, 0};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
-          acc = TR::mfma(A.x, B.x, acc);
-          acc = TR::mfma(A.y, B.y, acc);
-          acc = TR::mfma(A.z, B.z, acc);
-          acc = TR::mfma(A.w, B.w, acc);
+          acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
+          acc = t16_mfma<real, acc_t>(A.y, B.y, acc);
+          acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
+          acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * rt + TR::out_row(lane, r);
+#if T16_ABL == 3
+          if (k < W && j < W && acc[r] == real(-1.2345e300)) row[nd.off_w[d] + k * W + j] = acc[r];
+#else
           if (k < W && j < W) row[nd.off_w[d] + k * W + j] = old[r] + acc[r];
+#endif
         }
       }
       if (tid < W) {                          // bias gradient of layer d
@@ -340,12 +414,17 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
       V4* const Bnxt = TI;
       const real* __restrict__ Wd = th + nd.off_w[d];
-      for (int kt = wave; kt < NT; kt += 4) {
+      for (int kt = wave; kt < NT; kt += NWV) {
+        if (16 * kt >= W) {                   // tile entirely in the padding (wave-uniform): zeros
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Bnxt[(16 * kt + TR::out_row(lane, r)) * PD + m] = V4{0, 0, 0, 0};
+          continue;
+        }
         V4 sk[4];                             // stash of layer d-1 for this lane's four features (point m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * kt + TR::out_row(lane, r);
-          sk[r] = k < W ? S[((size_t)(d - 1) * W + k) * s_pad + lp0 + m] : V4{0, 0, 0, 0};
+          sk[r] = k < W ? S[T16_SIDX(((size_t)(d - 1) * W + k) * s_pad + lp0 + m)] : V4{0, 0, 0, 0};
         }
         acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
         const int k = 16 * kt + m;
@@ -355,32 +434,36 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
             const int jj = 4 * ks + g;
             const real a = wt[k * TLD + jj];
             const V4 b = Bcur[jj * PD + m];
-            a0 = TR::mfma(a, b.x, a0);
-            a1 = TR::mfma(a, b.y, a1);
-            a2 = TR::mfma(a, b.z, a2);
-            a3 = TR::mfma(a, b.w, a3);
+            a0 = t16_mfma<real, acc_t>(a, b.x, a0);
+            a1 = t16_mfma<real, acc_t>(a, b.y, a1);
+            a2 = t16_mfma<real, acc_t>(a, b.z, a2);
+            a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
         } else {                              // weights from L2, fetched one chunk of four k-steps ahead (see k_t16_fwd)
           const int nchunks = (ksteps + 3) >> 2;
-          real wc[4], wn[4];
+          real wq[T16_DEPTH + 1][4];
+          auto fetch = [&](int c, real (&dst)[4]) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int jj = 4 * u + g; wc[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0); }
+            for (int u = 0; u < 4; ++u) { const int jj = 4 * (4 * c + u) + g; dst[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0); }
+          };
+#pragma unroll
+          for (int q = 0; q < T16_DEPTH; ++q) fetch(q, wq[q]);
           for (int c = 0; c < nchunks; ++c) {
+            fetch(c + T16_DEPTH, wq[T16_DEPTH]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const int jj = 4 * (4 * (c + 1) + u) + g;
-              wn[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+              if (4 * c + u >= ksteps) break;
               const V4 b = Bcur[(4 * (4 * c + u) + g) * PD + m];
-              a0 = TR::mfma(wc[u], b.x, a0);
-              a1 = TR::mfma(wc[u], b.y, a1);
-              a2 = TR::mfma(wc[u], b.z, a2);
-              a3 = TR::mfma(wc[u], b.w, a3);
+              a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
+              a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
+              a2 = t16_mfma<real, acc_t>(wq[0][u], b.z, a2);
+              a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) wc[u] = wn[u];
+            for (int q = 0; q < T16_DEPTH; ++q) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
+            }
           }
         }
 #pragma unroll
@@ -391,11 +474,11 @@ __global__ __launch_bounds__(256) void k_t16_bwd(NetDesc nd, SetDesc sd, const r
       }
       __syncthreads();                        // every wave is done reading Bcur (adjoint GEMM): it is refilled
       if (d >= 2)                             // inputs of layer d-1 = output channels of layer d-2
-        for (int j = tid >> 4; j < WP; j += 16) {
+        for (int j = tid >> 4; j < WP; j += RP) {
           V4 c{0, 0, 0, 0};
           if (j < W) {
             real d1, d2;
-            c = channels_of(S[((size_t)(d - 2) * W + j) * s_pad + lp0 + pe], d1, d2);
+            c = channels_of(S[T16_SIDX(((size_t)(d - 2) * W + j) * s_pad + lp0 + pe)], d1, d2);
           }
           Bcur[j * PD + pe] = c;
         }

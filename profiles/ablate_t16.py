@@ -1,0 +1,59 @@
+"""Ablation of the shape-generic MFMA sweeps k_t16_fwd / k_t16_bwd on BASELINE configs[3] in float64 (Schrodinger, 4x100,
+N_f = 20000): -DT16_ABL=n builds of csrc/kernels_tile16.h with one ingredient compiled out at a time (results wrong by
+construction; only the kernel durations are read, from rocprofv3 --kernel-trace).
+    python profiles/ablate_t16.py --build [DIR]     # CPU: one libpinn_hip_t16abl{n}.so per variant (DIR default pinn_native/abl)
+    python profiles/ablate_t16.py [DIR]             # GPU: rocprofv3 over profiles/time_cfg4.py per variant"""
+import os, subprocess, sys, sqlite3, glob, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pinns-tf2.0_amd")
+NAMES = {0: "product kernels", 1: "no stash traffic (S stores / loads)", 2: "no matrix instructions",
+         3: "reverse: no read-modify-write of the gradient row", 4: "tanh -> one multiply"}
+
+
+def build(d):
+    os.makedirs(d, exist_ok=True)
+    hipcc = "/opt/rocm/bin/hipcc"
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+    procs = [(n, subprocess.Popen(common + ["-DT16_ABL=%d" % n, "-c", os.path.join(PKG, "csrc", "engine.hip"), "-o",
+                                            os.path.join(d, "engine_t16abl%d.o" % n)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for n in NAMES]
+    for n, p in procs:
+        out = p.communicate()[0]
+        if p.returncode:
+            raise SystemExit("variant %d failed:\n%s" % (n, out[-3000:]))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(d, "engine_t16abl%d.o" % n),
+                               os.path.join(PKG, "pinn_native", "fused20d_unit.o"), os.path.join(PKG, "pinn_native", "fused20m_unit.o"),
+                               "-o", os.path.join(d, "libpinn_hip_t16abl%d.so" % n), "-lrccl"])
+        os.remove(os.path.join(d, "engine_t16abl%d.o" % n))
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--build":
+    build(sys.argv[2] if len(sys.argv) > 2 else os.path.join(PKG, "pinn_native", "abl"))
+    raise SystemExit(0)
+d = sys.argv[1] if len(sys.argv) > 1 else os.path.join(PKG, "pinn_native", "abl")
+dtype = sys.argv[2] if len(sys.argv) > 2 else "f64"
+base = {}
+for n in NAMES:
+    lib = os.path.join(d, "libpinn_hip_t16abl%d.so" % n)
+    if not os.path.exists(lib):
+        continue
+    out_dir = "/tmp/t16abl_%d" % n
+    shutil.rmtree(out_dir, ignore_errors=True)
+    env = dict(os.environ, PINN_HIP_LIB=lib, TMPDIR="/tmp")
+    res = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", out_dir, "-o", "t", "--", sys.executable,
+                          os.path.join(ROOT, "profiles", "time_cfg4.py"), dtype, "10"], env=env, cwd="/tmp",
+                         capture_output=True, text=True)
+    step = [l for l in res.stdout.splitlines() if l.startswith("cfg4")]
+    dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+    t = {}
+    if dbs:
+        con = sqlite3.connect(dbs[0])
+        for name, avg in con.execute("select name, avg(end - start) from kernels group by name"):   # the `kernels` view of rocpd
+            for key in ("k_t16_fwd", "k_t16_bwd"):
+                if key in name:
+                    t[key] = avg / 1e3
+    if n == 0:
+        base = dict(t)
+    print("%d %-52s fwd %7.1f us (%+7.1f)   bwd %7.1f us (%+7.1f)   %s" % (
+        n, NAMES[n], t.get("k_t16_fwd", float("nan")), t.get("k_t16_fwd", 0) - base.get("k_t16_fwd", 0),
+        t.get("k_t16_bwd", float("nan")), t.get("k_t16_bwd", 0) - base.get("k_t16_bwd", 0), step[0].split(":")[1].split("->")[0] if step else "?"), flush=True)
