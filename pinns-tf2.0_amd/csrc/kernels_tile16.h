@@ -38,8 +38,15 @@ namespace pinn {
 #ifndef T16_WIDE_WAVES
 #define T16_WIDE_WAVES 8       // waves per workgroup of the float64 sweeps above width 64 (4 = the round-2 kernels)
 #endif
+#ifndef T16_AHEAD
+#define T16_AHEAD 0            // 1: the eight-wave reverse sweep fetches the row entries of all its dW tiles, and the next
+#endif                         // layer's stash, ahead of the matrix instructions -- measured 8 us SLOWER on cfg 4 float64
+                               // (605 vs 597 us, same box, profiles/r03_t16_ab.txt): with two waves per SIMD the other
+                               // wave already covers those latencies and the extra live registers cost more
 #ifndef T16_DEPTH
-#define T16_DEPTH 2            // chunks of four k-steps of L2-resident weights in flight ahead of the one in use
+#define T16_DEPTH 2            // eight-wave variants: chunks of four k-steps of L2-resident weights in flight ahead of the
+                               // one in use (2 vs 1: 583 vs 605 us on cfg 4 float64, profiles/r03_t16_ab.txt); the
+                               // four-wave variants keep 1 (2, 3, 4 measured there: no gain, profiles/r03_t16_depth.txt)
 #endif
 template <typename real> __device__ __forceinline__ real tanh_mm(real z);
 template <> __device__ __forceinline__ float tanh_mm<float>(float z) { return tanhf(z); }
@@ -201,18 +208,19 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_fwd(NetDesc nd, const real* __
           const int nchunks = (ksteps + 3) >> 2;
           // T16_DEPTH chunks in flight: an L2 hit costs ~1.5 k cycles here, one chunk of float64 matrix instructions
           // lasts 1 k (ablation, profiles/r03_ablate_t16_f64.txt: with one chunk ahead every chunk stalled)
-          real wq[T16_DEPTH + 1][4];
+          constexpr int DEPTH = NWV == 8 ? T16_DEPTH : 1;
+          real wq[DEPTH + 1][4];
           auto fetch = [&](int c, real (&dst)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int k = 4 * (4 * c + u) + g; dst[u] = (k < W && ja < W) ? Wl[k * W + ja] : real(0); }
           };
 #pragma unroll
-          for (int q = 0; q < T16_DEPTH; ++q) fetch(q, wq[q]);
+          for (int q = 0; q < DEPTH; ++q) fetch(q, wq[q]);
           for (int c = 0; c < nchunks; ++c) {
-            fetch(c + T16_DEPTH, wq[T16_DEPTH]);
+            fetch(c + DEPTH, wq[DEPTH]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              if (4 * c + u >= ksteps) break;                      // last chunk: only the k-steps that exist (uniform)
+              if (NWV == 8 && 4 * c + u >= ksteps) break;          // last chunk: only the k-steps that exist (uniform)
               const V4 b = Tin[(4 * (4 * c + u) + g) * PD + m];
               a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
               a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_fwd(NetDesc nd, const real* __
               a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
             }
 #pragma unroll
-            for (int q = 0; q < T16_DEPTH; ++q) {
+            for (int q = 0; q < DEPTH; ++q) {
 #pragma unroll
               for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
             }
@@ -373,18 +381,48 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
       }
       // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j
       const int ntl = (W + 15) >> 4;                              // live tiles per side: the others are padding
-      for (int tau = wave; tau < ntl * ntl; tau += NWV) {
+      // The row entries a tile updates are fetched for ALL of this wave's tiles before its first matrix instruction
+      // (MAXT x 4 registers): the partial rows of 256 workgroups do not fit the L2s, a fetch costs 2-3 k cycles and a
+      // tile's 16 matrix instructions last 1 k, so fetching per tile stalled every tile (ablation, float64 width 100,
+      // profiles/r03_ablate_t16_f64.txt: the read-modify-write was 83 of 434 us).  Same thread reads and writes an
+      // entry, group after group: program order keeps the accumulation exact.
+      constexpr int MAXT = (NT * NT + NWV - 1) / NWV;
+      constexpr bool AHEAD = NWV == 8 && T16_AHEAD;   // (the four-wave variants keep the per-tile fetch: they were tuned, and
+                                              //  are launched, for two or three workgroups per CU at their register count)
+      real oldv[AHEAD ? MAXT : 1][4];
+      if constexpr (AHEAD) {
+#pragma unroll
+        for (int ti = 0; ti < MAXT; ++ti) {
+          const int tau = wave + ti * NWV;
+          const int rt = tau / ntl, ct = tau - rt * ntl, j = 16 * ct + m;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int k = 16 * rt + TR::out_row(lane, r);
+#if T16_ABL == 3
+            oldv[ti][r] = real(0);
+#else
+            oldv[ti][r] = (tau < ntl * ntl && k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
+#endif
+          }
+        }
+      }
+#pragma unroll
+      for (int ti = 0; ti < (AHEAD ? MAXT : 1); ++ti)
+      for (int tau = wave + ti * NWV; tau < ntl * ntl; tau += (AHEAD ? NT * NT * NWV : NWV)) {   // AHEAD: one tile per ti
         const int rt = tau / ntl, ct = tau - rt * ntl;
         const int j = 16 * ct + m;
-        real old[4];                                              // the row entries to update: fetched under the MFMAs
+        real old[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * rt + TR::out_row(lane, r);
+          if constexpr (AHEAD) old[r] = oldv[ti][r];
+          else {
 #if T16_ABL == 3
-          old[r] = real(0);
+            old[r] = real(0);
 #else
-          old[r] = (k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
+            old[r] = (k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
 #endif
+          }
         }
         acc_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -413,6 +451,17 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
       __syncthreads();                        // every wave is done reading TI (dW): it becomes the output tile
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
       V4* const Bnxt = TI;
+      // the stash of layer d-2 (inputs of the next layer down, written into the tile after this GEMM) is requested
+      // now, so that its HBM latency runs under the matrix instructions instead of after them
+      constexpr int NREF = WP / RP;
+      V4 sref[AHEAD ? NREF : 1];
+      if (AHEAD && d >= 2) {
+#pragma unroll
+        for (int i = 0; i < NREF; ++i) {
+          const int j = (tid >> 4) + RP * i;
+          sref[AHEAD ? i : 0] = j < W ? S[T16_SIDX(((size_t)(d - 2) * W + j) * s_pad + lp0 + pe)] : V4{0, 0, 0, 0};
+        }
+      }
       const real* __restrict__ Wd = th + nd.off_w[d];
       for (int kt = wave; kt < NT; kt += NWV) {
         if (16 * kt >= W) {                   // tile entirely in the padding (wave-uniform): zeros
@@ -441,18 +490,19 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
           }
         } else {                              // weights from L2, fetched one chunk of four k-steps ahead (see k_t16_fwd)
           const int nchunks = (ksteps + 3) >> 2;
-          real wq[T16_DEPTH + 1][4];
+          constexpr int DEPTH = NWV == 8 ? T16_DEPTH : 1;
+          real wq[DEPTH + 1][4];
           auto fetch = [&](int c, real (&dst)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) { const int jj = 4 * (4 * c + u) + g; dst[u] = (k < W && jj < W) ? Wd[k * W + jj] : real(0); }
           };
 #pragma unroll
-          for (int q = 0; q < T16_DEPTH; ++q) fetch(q, wq[q]);
+          for (int q = 0; q < DEPTH; ++q) fetch(q, wq[q]);
           for (int c = 0; c < nchunks; ++c) {
-            fetch(c + T16_DEPTH, wq[T16_DEPTH]);
+            fetch(c + DEPTH, wq[DEPTH]);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              if (4 * c + u >= ksteps) break;
+              if (NWV == 8 && 4 * c + u >= ksteps) break;
               const V4 b = Bcur[(4 * (4 * c + u) + g) * PD + m];
               a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
               a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
@@ -460,7 +510,7 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
               a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
             }
 #pragma unroll
-            for (int q = 0; q < T16_DEPTH; ++q) {
+            for (int q = 0; q < DEPTH; ++q) {
 #pragma unroll
               for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
             }
@@ -473,15 +523,19 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
         }
       }
       __syncthreads();                        // every wave is done reading Bcur (adjoint GEMM): it is refilled
-      if (d >= 2)                             // inputs of layer d-1 = output channels of layer d-2
-        for (int j = tid >> 4; j < WP; j += RP) {
+      if (d >= 2) {                           // inputs of layer d-1 = output channels of layer d-2
+#pragma unroll
+        for (int i = 0; i < NREF; ++i) {
+          const int j = (tid >> 4) + RP * i;
           V4 c{0, 0, 0, 0};
           if (j < W) {
             real d1, d2;
-            c = channels_of(S[T16_SIDX(((size_t)(d - 2) * W + j) * s_pad + lp0 + pe)], d1, d2);
+            if constexpr (AHEAD) c = channels_of(sref[i], d1, d2);
+            else c = channels_of(S[T16_SIDX(((size_t)(d - 2) * W + j) * s_pad + lp0 + pe)], d1, d2);
           }
           Bcur[j * PD + pe] = c;
         }
+      }
       V4* tmp = Bcur; Bcur = TI; TI = tmp;     // roles swap: the old TI holds z_bar, the old Bcur the inputs
     }
     __syncthreads();                          // z_bar of dense 0 published (also covers H == 1)
