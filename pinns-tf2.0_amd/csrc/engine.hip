@@ -369,6 +369,7 @@ static int ensure_sets(pinn_ctx* c) {
   // the fused kernel keeps the whole set's stash (one launch); the generic path works in chunks
   const size_t stash_pts = c->path == 1 ? (size_t)n_pad : (size_t)c->chunk;
   c->n_wg = (n_pad / 64 < c->n_cu) ? n_pad / 64 : c->n_cu;   // persistent workgroups (paths 2 and 7)
+  if (c->path == 7) c->n_wg = fused20d_plan(n_pad, c->n_cu).n_wg;   // ... or 48-point tiles with a helper wave
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
   const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : (c->path == 2 || c->path == 7) ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
   const bool no_stash = c->path == 2 || c->path == 7;
@@ -506,8 +507,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     if constexpr (sizeof(real) == 8 && PDE != 2)
       rc = fused20d_launch_any(PDE, c->nd, sd, (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts,
                                (const double*)c->tgt, (double)lbx, (double)lbt, (double)sx, (double)st,
-                               (double)c->nu, (double*)c->part, c->R, c->n_wg, c->row_index, c->stream, c->stamps,
-                               ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
+                               (double)c->nu, (double*)c->part, c->R, fused20d_plan(sd.n_pad, c->n_cu), c->row_index,
+                               c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
     if (rc) return fail(PINN_EHIP, "fused20d launch failed: %s", hipGetErrorString((hipError_t)rc));
   } else if (c->path == 2) {
     int rc = hipErrorInvalidValue;
@@ -1047,7 +1048,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   }
   if (fused_regs_ok(c)) nd.img_kind = 1;
   if (fused_f64_ok(c)) {
-    std::vector<int> ri((size_t)fused20d_blocks(nd.n_hidden) * 16);
+    std::vector<int> ri((size_t)fused20d_blocks(nd.n_hidden) * 16 * 2);   // + the slot table of k_fused20dh
     fused20d_row_index(nd, nd.n_hidden, ri.data());
     if (dev_alloc(&c->row_index, ri.size() * sizeof(int))) { delete c; return PINN_EHIP; }
     HIPCHK(hipMemcpy(c->row_index, ri.data(), ri.size() * sizeof(int), hipMemcpyHostToDevice));

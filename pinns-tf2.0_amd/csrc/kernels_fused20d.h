@@ -49,6 +49,7 @@ namespace pinn {
 #define PINN_ABLD 0
 #endif
 
+
 // a double parked in the accumulation half of the register file (two 32-bit AGPRs)
 struct agd { int lo, hi; };
 __device__ __forceinline__ agd agd_put(const double x) {

@@ -489,7 +489,7 @@ class Engine(object):
 
     def debug_stamps(self):
         """(profiling build) -> int64 array [n_waves, 32] of s_memtime ticks for one evaluation"""
-        n_wg = (2 * self.n_b + self.n_u + self.n_f + 63) // 64
+        n_wg = (2 * self.n_b + self.n_u + self.n_f + 63) // 64 * 2      # (48-point tiles of k_fused20dh: up to 4/3 as many)
         buf = np.zeros((n_wg * 4, 32), dtype=np.int64)
         n = ctypes.c_int64(0)
         self._check(self._lib.pinn_debug_stamps(

@@ -55,6 +55,24 @@ def main():
     for i, nme in enumerate(names):
         print("%-34s %10.0f %10.0f %10.0f" % (nme, np.median(per[:, i]), per[:, i].min(), per[:, i].max()))
     print("%-34s %10.0f" % ("sum of medians", np.median(per, axis=0).sum()))
+    if path == 7 and st.shape[0] != (n_f + 100 + 63) // 64:         # k_fused20dh: waves 0-2 = mains, wave 3 = helper
+        print("# helper-wave variant (48-point tiles): mains (slowest of waves 0-2) | helper wave, medians over workgroups")
+        pm, ph = dur[:, :3, :].max(axis=1), dur[:, 3, :]
+        for i, nme in enumerate(names):
+            print("%-34s %10.0f %10.0f" % (nme, np.median(pm[:, i]), np.median(ph[:, i])))
+        full = eng.debug_stamps().astype(np.float64).reshape(-1, 4, 32)
+        H_ = H
+        def segm(a, b):
+            return np.median((full[:, :3, b] - full[:, :3, a]).max(axis=1))
+        def segh(a, b):
+            return np.median(full[:, 3, b] - full[:, 3, a])
+        prev = 2 * H_ + 1 - 5                            # end of layer 5 = start of layer 4
+        print("# layer 4, mains: adjoints+channels %.0f | wait consumed %.0f | park+flag %.0f | read back %.0f | own dW %.0f | GEMV %.0f" % (
+            segm(prev, 20), segm(20, 21), segm(21, 22), segm(22, 23), segm(23, 24), segm(24, 2 * H_ + 1 - 4)))
+        print("# layer 4, helper: after layer 5 .. poll %.0f | wait ready(main 0) %.0f | main 0 %.0f | main 1 %.0f | main 2 %.0f | folds+stores %.0f" % (
+            segh(prev, 20), segh(20, 21), segh(21, 22), segh(22, 23), segh(23, 24), segh(24, 2 * H_ + 1 - 4)))
+        print("%-34s %10.0f %10.0f" % ("whole wave (first to last stamp)", np.median((st[:, :3, -1] - st[:, :3, 0]).max(axis=1)),
+                                       np.median(st[:, 3, -1] - st[:, 3, 0])))
     if path == 2:
         full = eng.debug_stamps().astype(np.float64).reshape(-1, 4, 32)
         H_ = H
