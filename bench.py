@@ -313,7 +313,8 @@ def pmc_traffic(dtype, n_f_total, world, path):
     if world != 1 or n_f_total not in (10000, 1000000):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+        name = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
             j = json.load(fh)
         if j.get("kernel_path_" + dtype) != path:
             return None

@@ -41,7 +41,8 @@ for nf in (125000, 1000000):
     np.random.seed(1234)
     r = burgersutil.prep_data(os.path.join(bench.PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, nf, noise=0.0)
     X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
-    eng = pinn_native.Engine(bench.LAYERS, lb, ub, pde="burgers", dtype="f32")
-    eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(bench.NU); eng.set_weights(bench.canonical_weights())
-    s = timeit(eng, 20)
-    print("cfg5 burgers f32 N_f=%d path=%d: %.1f us/Adam step -> %.3g pts/s (%.1f TFLOP/s)" % (nf, eng.kernel_path(), s * 1e6, nf / s, nf / s * 68640 / 1e12)); eng.close()
+    for dt in ("f32", "f64"):
+        eng = pinn_native.Engine(bench.LAYERS, lb, ub, pde="burgers", dtype=dt)
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(bench.NU); eng.set_weights(bench.canonical_weights())
+        s = timeit(eng, 20)
+        print("cfg5 burgers %s N_f=%d path=%d: %.1f us/Adam step -> %.3g pts/s (%.1f TFLOP/s)" % (dt, nf, eng.kernel_path(), s * 1e6, nf / s, nf / s * 68640 / 1e12)); eng.close()
