@@ -249,8 +249,14 @@ static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6;
 //     workgroups per CU; many groups -> weights staged in LDS, two workgroups per CU;
 //   widths <= 64, float64: weights from L2 (the LDS copy would leave room for one workgroup per CU only), two per CU;
 //   widths > 64: two per CU (float32: weights in LDS; float64: from L2, LDS is full).
+// widths above 64 in float32: 1 = the eight-wave variant with the weights read from L2 (as float64 does), 0 = round 2's
+// four waves with the layer's weights staged in LDS
+#ifndef T16_F32_WIDE8
+#define T16_F32_WIDE8 1
+#endif
+static constexpr bool T16_WIDE_F32_LDS = !T16_F32_WIDE8;
 static bool t16_lds_weights(const pinn_ctx* c, int pts) {
-  if (c->nd.width > 64) return c->dtype != PINN_F64;
+  if (c->nd.width > 64) return c->dtype != PINN_F64 && T16_WIDE_F32_LDS;
   if (c->dtype == PINN_F64) return false;
   return pts / 16 > 3 * c->n_cu;
 }
@@ -263,8 +269,9 @@ static int t16_wgs(const pinn_ctx* c, int pts) {
   const size_t rs = c->dtype == PINN_F64 ? 8 : 4;
   size_t lds;
   if (c->nd.width > 64) {
-    const bool wl = rs == 4;
+    const bool wl = rs == 4 && T16_WIDE_F32_LDS;
     lds = t16_fwd_lds<8>(rs, wl) > t16_bwd_lds<8>(rs, wl) ? t16_fwd_lds<8>(rs, wl) : t16_bwd_lds<8>(rs, wl);
+    if (!wl) per_cu = 1;                       // the eight-wave variants: one workgroup = two waves per SIMD
   } else {
     const bool wl = t16_lds_weights(c, pts);
     lds = t16_fwd_lds<4>(rs, wl) > t16_bwd_lds<4>(rs, wl) ? t16_fwd_lds<4>(rs, wl) : t16_bwd_lds<4>(rs, wl);
@@ -433,7 +440,7 @@ static int t16_launch_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad
                           real lbx, real lbt, real sx, real st) {
   static unsigned long long attr = 0;
   // eight waves per workgroup where LDS admits one workgroup per CU only (float64, widths above 64): two waves per SIMD
-  constexpr int NWV = (sizeof(real) == 8 && NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
+  constexpr int NWV = (NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
   const size_t lds = t16_fwd_lds<NT>(sizeof(real), WLDS, NWV);
   if (first_call_on_device(attr))
     HIPCHK(hipFuncSetAttribute((const void*)k_t16_fwd<real, NT, WLDS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -446,7 +453,7 @@ static int t16_launch_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad
 template <typename real, int NT, int PDE, bool WLDS>
 static int t16_launch_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
   static unsigned long long attr = 0;
-  constexpr int NWV = (sizeof(real) == 8 && NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
+  constexpr int NWV = (NT == 8 && !WLDS) ? T16_WIDE_WAVES : 4;
   const size_t lds = t16_bwd_lds<NT>(sizeof(real), WLDS);
   if (first_call_on_device(attr))
     HIPCHK(hipFuncSetAttribute((const void*)k_t16_bwd<real, NT, PDE, WLDS, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -466,7 +473,7 @@ static int t16_fwd(pinn_ctx* c, const void* xs, const void* ts, int n_pad, int c
                    real lbx, real lbt, real sx, real st) {
   // widths up to 64: four feature tiles; up to 128: eight (in float64 the weights then stay in L2: LDS is full)
   if (c->nd.width > 64)
-    return t16_launch_fwd<real, 8, sizeof(real) == 4>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
+    return t16_launch_fwd<real, 8, sizeof(real) == 4 && T16_WIDE_F32_LDS>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
   if (!t16_lds_weights(c, pts))
     return t16_launch_fwd<real, 4, false>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
   return t16_launch_fwd<real, 4, true>(c, xs, ts, n_pad, chunk, O, base, pts, lbx, lbt, sx, st);
@@ -488,7 +495,7 @@ static int forward_chunk(pinn_ctx* c, const void* xs, const void* ts, int n_pad,
 template <typename real, int PDE>
 static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, real st, int accumulate) {
   if (c->nd.width > 64)
-    return t16_launch_bwd<real, 8, PDE, sizeof(real) == 4>(c, base, pts, lbx, lbt, sx, st, accumulate);
+    return t16_launch_bwd<real, 8, PDE, sizeof(real) == 4 && T16_WIDE_F32_LDS>(c, base, pts, lbx, lbt, sx, st, accumulate);
   if (!t16_lds_weights(c, pts))
     return t16_launch_bwd<real, 4, PDE, false>(c, base, pts, lbx, lbt, sx, st, accumulate);
   return t16_launch_bwd<real, 4, PDE, true>(c, base, pts, lbx, lbt, sx, st, accumulate);

@@ -1,6 +1,6 @@
 """BASELINE configs[3] (1dcomplex-schrodinger/inf_cont_schrodinger.py: 2-100-100-100-100-2 net, N_f = 20000, N_0 = N_b = 50)
 Adam-step time in float64 and float32; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split.
-    python profiles/time_cfg4.py [f64|f32|both] [steps]"""
+    python profiles/time_cfg4.py [f64|f32|both] [steps] [kernel path]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,7 @@ from oracle import init
 
 which = sys.argv[1] if len(sys.argv) > 1 else "both"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+force_path = int(sys.argv[3]) if len(sys.argv) > 3 else -1
 np.random.seed(1234)
 r = schrodingerutil.prep_data(os.path.join(bench.PKG, "1dcomplex-schrodinger", "data", "NLS.mat"), 50, 50, 20000, noise=0.0)
 X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
@@ -22,6 +23,8 @@ for dt in (("f64", "f32") if which == "both" else (which,)):
     eng = pinn_native.Engine(layers, lb, ub, pde="schrodinger", dtype=dt)
     eng.set_collocation(X_f); eng.set_boundary(np.concatenate((0 * tb + lb[0], tb), 1), np.concatenate((0 * tb + ub[0], tb), 1))
     eng.set_data(X0, np.concatenate([u0, v0], 1)); eng.set_weights(init.glorot_flat(layers))
+    if force_path >= 0:
+        eng.set_kernel_path(force_path)
     eng.loss_grad(); eng.adam_init(1e-3, 0.9, 0.999, 1e-7); eng.adam_run(5, want_losses=False); eng.sync()
     best = 1e9
     for rep in range(3):
