@@ -38,6 +38,9 @@ namespace pinn {
 #ifndef T16_WIDE_WAVES
 #define T16_WIDE_WAVES 8       // waves per workgroup of the float64 sweeps above width 64 (4 = the round-2 kernels)
 #endif
+#ifndef T16_SKIP_FIRST
+#define T16_SKIP_FIRST 1
+#endif
 #ifndef T16_AHEAD
 #define T16_AHEAD 0            // 1: the eight-wave reverse sweep fetches the row entries of all its dW tiles, and the next
 #endif                         // layer's stash, ahead of the matrix instructions -- measured 8 us SLOWER on cfg 4 float64
@@ -420,7 +423,10 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
 #if T16_ABL == 3
             old[r] = real(0);
 #else
-            old[r] = (k < W && j < W) ? row[nd.off_w[d] + k * W + j] : real(0);
+            // the first group of a fresh row adds to the zeros this workgroup has just written: nothing to fetch
+            // (eight-wave variants; one fifth of the row reads at five groups per workgroup)
+            old[r] = (k < W && j < W && !(NWV == 8 && T16_SKIP_FIRST && !accumulate && grp == (int)blockIdx.x))
+                         ? row[nd.off_w[d] + k * W + j] : real(0);
 #endif
           }
         }
