@@ -46,6 +46,10 @@ namespace pinn {
 //   1 no dW matrix instructions     2 no group-4 chain, exchange and its barrier     3 workgroup barriers -> LDS waits only
 //   4 tanh -> one multiply          5 no AGPR stash traffic                          6 no adjoint / channel arithmetic in phase A
 //   7 no own-group GEMV matrix instructions
+//   8 UPPER BOUND of "recompute instead of stash, two workgroups per CU" (VERDICT r2 item 7): the stash of every second
+//     layer is dropped (a constant is read back: no recompute is paid for), one exchange-tile pair instead of two, no
+//     dW partial sum in the epilogue -> 72 KB of LDS, __launch_bounds__(256, 2), grid = 2 x CUs.  What it measures is
+//     the most two waves per SIMD could give this kernel BEFORE the +1/6 matrix work of the recompute.
 #ifndef PINN_ABL
 #define PINN_ABL 0
 #endif
@@ -138,7 +142,11 @@ constexpr int fused20m_xchg_v4(int n_hidden) {
   return tiles > epi ? tiles : epi;
 }
 inline size_t fused20m_lds_bytes(int n_hidden) {
+#if PINN_ABL == 8
+  return fused20m_image_floats(n_hidden) * 4 + (size_t)(2 * FROWS + 4) * 65 * 16;
+#else
   return fused20m_image_floats(n_hidden) * 4 + (size_t)fused20m_xchg_v4(n_hidden) * 16;
+#endif
 }
 
 // Called by every kernel that writes a weight: mirrors flat parameter i into the LDS image.
@@ -218,8 +226,15 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
 // ONE_TILE: the launch has at least as many workgroups as tiles (the 10^4-point headline), so the
 // tile loop is a single pass: no loop-carried coordinate prefetch, which lets the compiler wait for
 // the first coordinates without also draining the image DMA issued behind them.
+#if PINN_ABL == 8
+#define PINN_F20M_BOUNDS __launch_bounds__(256, 2)
+#define PINN_STASH_KEEP(d) ((((d) & 1) == 0))
+#else
+#define PINN_F20M_BOUNDS __launch_bounds__(256)
+#define PINN_STASH_KEEP(d) true
+#endif
 template <int PDE, int H, bool ONE_TILE>
-__global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
+__global__ PINN_F20M_BOUNDS void k_fused20m(NetDesc nd, SetDesc sd,
                                                   const float* __restrict__ th,
                                                   const float* __restrict__ img,
                                                   const float* __restrict__ xs,
@@ -234,7 +249,11 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* const wl = reinterpret_cast<float*>(lds_raw);
   v4f* const xb = reinterpret_cast<v4f*>(wl + NW);
+#if PINN_ABL == 8
+  v4f* const Q = xb + 2 * BUFV;
+#else
   v4f* const Q = xb + 4 * BUFV;                     // group-4 meeting point: [4][RS4] float4
+#endif
   float* const Qf = reinterpret_cast<float*>(Q);
 
   STAMP(0);
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     for (int jj = 0; jj < FF; ++jj) {            // dense 0: p0 = (sx, 0), q0 = (0, st), r0 = 0
       const float z = fmaf(hx, w0x[jj], fmaf(ht, w0t[jj], b0[jj]));
       const v4f s{tanh_r5(z), sx * w0x[jj], st * w0t[jj], 0.0f};
-      stash[0][jj] = agpr_put4(s);
+      stash[0][jj] = PINN_STASH_KEEP(0) ? agpr_put4(s) : v4f{0.25f, 0.5f, 0.25f, 0.5f};
       xb[feat(jj) * RS4 + lane] = channels4(s);
     }
     if (image_pending) {                         // the pre-loaded patterns have arrived (same round trip as x, t)
@@ -382,7 +401,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const v4f s{tanh_r5(acc_own[0][jj]), acc_own[1][jj], acc_own[2][jj], acc_own[3][jj]};
-        stash[d][jj] = agpr_put4(s);
+        stash[d][jj] = PINN_STASH_KEEP(d) ? agpr_put4(s) : v4f{0.25f, 0.5f, 0.25f, 0.5f};
         Xout[(4 * wave + jj) * RS4 + lane] = channels4(s);
       }
       if (d == 4) STAMP(26);
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
         const v4f z4 = Q[wave * RS4 + lane];      // feature 16+wave: (h, p, q, r) pre-activations
 #endif
         const v4f s{tanh_r5(z4.x), z4.y, z4.z, z4.w};
-        stash[d][4] = agpr_put4(s);
+        stash[d][4] = PINN_STASH_KEEP(d) ? agpr_put4(s) : v4f{0.25f, 0.5f, 0.25f, 0.5f};
         Xout[(16 + wave) * RS4 + lane] = channels4(s);
       }
       if (d == 1 && image_pending) {             // first tile only: this wave's DMA pieces have landed
@@ -448,7 +467,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
       gHb += sb.x;
 #pragma unroll
       for (int kk = 0; kk < FF; ++kk) {
-        const v4f in = channels4(agpr_get4(stash[H - 1][kk]));
+        const v4f in = channels4(PINN_STASH_KEEP(H - 1) ? agpr_get4(stash[H - 1][kk]) : stash[H - 1][kk]);
         gH[kk] += fmaf(in.w, sb.w, fmaf(in.z, sb.z, fmaf(in.y, sb.y, in.x * sb.x)));
         ob[kk] = sb * wLo[kk];
       }
@@ -457,14 +476,18 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     STAMP(H + 1);
 #pragma unroll
     for (int d = H - 1; d >= 1; --d) {
+#if PINN_ABL == 8
+      const int pair = 0;
+#else
       const int pair = (H - 1 - d) & 1;
+#endif
       v4f* __restrict__ IN = xb + (2 * pair) * BUFV;
       v4f* __restrict__ ZB = xb + (2 * pair + 1) * BUFV;
       // phase A: publish own z_bar (layer d) and own layer-(d-1) output channels
 #pragma unroll
       for (int kk = 0; kk < FF; ++kk) {
-        ZB[feat(kk) * RS4 + lane] = preact_adjoint4(agpr_get4(stash[d][kk]), ob[kk]);
-        IN[feat(kk) * RS4 + lane] = channels4(agpr_get4(stash[d - 1][kk]));
+        ZB[feat(kk) * RS4 + lane] = preact_adjoint4(PINN_STASH_KEEP(d) ? agpr_get4(stash[d][kk]) : stash[d][kk], ob[kk]);
+        IN[feat(kk) * RS4 + lane] = channels4(PINN_STASH_KEEP(d - 1) ? agpr_get4(stash[d - 1][kk]) : stash[d - 1][kk]);
       }
       if (d == 4) STAMP(28);
       lds_barrier();
@@ -526,7 +549,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
 #pragma unroll
       for (int kk = 0; kk < FF; ++kk) {
-        const v4f zb = preact_adjoint4(agpr_get4(stash[0][kk]), ob[kk]);
+        const v4f zb = preact_adjoint4(PINN_STASH_KEEP(0) ? agpr_get4(stash[0][kk]) : stash[0][kk], ob[kk]);
         g0x[kk] += fmaf(hx, zb.x, sx * zb.y);
         g0t[kk] += fmaf(ht, zb.x, st * zb.z);
         g0b[kk] += zb.x;
@@ -547,12 +570,18 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     // behind the four waves' row areas: the weight-gradient partials, [wave][layer][main|fringe][lane]
     constexpr int PSW = (H - 1) * 2 * 64;            // float4 per wave
     v4f* const psum = xb + NV * RSF;
+#if PINN_ABL != 8
     static_assert(NV * RSF + 4 * PSW <= fused20m_xchg_v4(H), "partials fit in the exchange area");
+#endif
+#if PINN_ABL != 8
 #pragma unroll
     for (int d = 1; d < H; ++d) {
       psum[wave * PSW + ((d - 1) * 2 + 0) * 64 + lane] = dwm[d];
       psum[wave * PSW + ((d - 1) * 2 + 1) * 64 + lane] = dwf[d];
     }
+#else
+    if (lane == 77) { for (int d = 1; d < H; ++d) row[d] = dwm[d].x + dwf[d].x; }      // (keeps the accumulators alive)
+#endif
 #pragma unroll
     for (int kk = 0; kk < FF; ++kk) {
       red[(0 + kk) * RSF + lane] = g0x[kk];
@@ -590,6 +619,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
     // taking layers w+1, w+5, ...  b_d sits right behind W_d in the flat layout, so input-feature row
     // 20 (the ones row) lands on the bias.
     lds_barrier();
+#if PINN_ABL != 8
     const int km = 4 * (lane >> 4), jm = lane & 15;              // main block: VGPR r -> input feature km + r
     const int kf = 4 * fkg, jf = 4 * fjg + (lane & 3);           // fringe block: VGPR r -> input feature kf + r
     const bool okf = fblk <= 13;
@@ -608,6 +638,7 @@ __global__ __launch_bounds__(256) void k_fused20m(NetDesc nd, SetDesc sd,
         }
       }
     }
+#endif
   }
   STAMP(2 * H + 2);
 }

@@ -1,0 +1,35 @@
+"""Upper bound of "recompute instead of stash, two workgroups per CU" for k_fused20m: Adam-step
+time of the -DPINN_ABL=8 build (csrc/kernels_fused20m.h: every second layer's stash dropped WITHOUT paying the recompute,
+one exchange-tile pair, 72 KB LDS, __launch_bounds__(256, 2), grid = 2 x CUs; results wrong by construction) against the
+product kernel, float32, in the throughput regime.
+    hipcc ... -DPINN_ABL=8 -c csrc/engine.hip; link with the two other units -> pinn_native/abl/libpinn_hip_abl8.so
+    python profiles/ablate_two_wg.py"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = r'''
+import os, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+import bench, burgersutil, pinn_native
+for nf in (10000, 125000, 1000000):
+    np.random.seed(1234)
+    r = burgersutil.prep_data(os.path.join(bench.PKG, "1d-burgers", "data", "burgers_shock.mat"), 100, nf, noise=0.0)
+    eng = pinn_native.Engine(bench.LAYERS, r[11], r[10], pde="burgers", dtype="f32")
+    eng.set_collocation(r[9]); eng.set_data(r[7], r[8]); eng.set_pde_params(bench.NU); eng.set_weights(bench.canonical_weights())
+    eng.adam_init(1e-3, 0.9, 0.999, 1e-7); eng.adam_run(10, want_losses=False); eng.sync()
+    best = 1e9
+    for rep in range(3):
+        n = 200 if nf == 10000 else 20
+        t0 = time.perf_counter(); eng.adam_run(n, want_losses=False); eng.sync()
+        best = min(best, (time.perf_counter() - t0) / n)
+    print("N_f=%%7d: %%8.1f us per Adam step, %%.3g points/s, %%.1f TFLOP/s" %% (nf, best * 1e6, nf / best, nf / best * 68640 / 1e12), flush=True)
+    eng.close()
+''' % {"root": ROOT}
+for name, lib in (("product k_fused20m (one workgroup per CU, full AGPR stash)", None),
+                  ("-DPINN_ABL=8: two workgroups per CU, half the stash, no recompute paid (upper bound)",
+                   os.path.join(ROOT, "pinns-tf2.0_amd", "pinn_native", "abl", "libpinn_hip_abl8.so"))):
+    env = dict(os.environ)
+    if lib:
+        env["PINN_HIP_LIB"] = lib
+    print("== " + name, flush=True)
+    print(subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout, flush=True)
