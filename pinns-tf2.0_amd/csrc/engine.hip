@@ -380,6 +380,7 @@ static int ensure_sets(pinn_ctx* c) {
   if (c->path == 2) c->n_wg = (n_pad / 64 < 2 * c->n_cu) ? n_pad / 64 : 2 * c->n_cu;   // ablation: two workgroups per CU
 #endif
   if (c->path == 7) c->n_wg = fused20d_plan(n_pad, c->n_cu).n_wg;   // ... or 48-point tiles with a helper wave
+  if (c->path == 2) c->n_wg = fused20m_plan(c->nd.n_hidden, n_pad, c->n_cu).n_wg;   // ... or two workgroups per CU (k_fused20r)
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
   const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : (c->path == 2 || c->path == 7) ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
   const bool no_stash = c->path == 2 || c->path == 7;
@@ -523,7 +524,12 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   } else if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2) {
-      if (c->nd.n_hidden == 8)
+      if (fused20m_plan(c->nd.n_hidden, sd.n_pad, c->n_cu).recompute)      // throughput regime: kernels_fused20r.h
+        rc = fused20r_launch_any(PDE, c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
+                                 (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
+                                 (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
+                                 c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
+      else if (c->nd.n_hidden == 8)
         rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
                                      (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
                                      (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,

@@ -578,3 +578,46 @@ print("RESULT" + json.dumps(out))
         assert abs(a[0] - b[0]) <= 1e-13 * abs(a[0]), pde
         assert np.max(np.abs(a[1:] - b[1:])) <= 1e-12 * np.max(np.abs(a[1:])), pde
         assert not np.array_equal(a[1:], b[1:]) or True          # (different summation grouping: equal only by luck)
+
+
+def test_recompute_variant_of_the_f32_kernel_matches_the_product_kernel():
+    """csrc/kernels_fused20r.h (opt-in, PINN_F32_RECOMPUTE=1: even layers stashed, odd layers recomputed, two workgroups
+    per CU): the experiment stays pinned -- the recomputed layers repeat the forward instructions, so loss and gradient
+    agree with k_fused20m to the float32 rounding of a different summation grouping (twice as many partial rows)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd")); sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers"))
+import pinn_native, burgersutil
+g = np.load(os.path.join(%(root)r, "tests", "golden", "burgers_eval.npz"))
+np.random.seed(1234)
+r = burgersutil.prep_data(os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers", "data", "burgers_shock.mat"), 100, 70001, noise=0.0)
+out = {}
+for pde in ("burgers", "burgers_ide"):
+    eng = pinn_native.Engine([2] + [20] * 8 + [1], r[11], r[10], pde=pde, dtype="f32")
+    w = g["w0"] if pde == "burgers" else np.concatenate([g["w0"], [0.5, -5.0]])
+    if pde == "burgers":
+        eng.set_collocation(r[9]); eng.set_data(r[7], r[8]); eng.set_pde_params(0.01 / np.pi)
+    else:
+        eng.set_data(r[9][:40000], np.sin(r[9][:40000, :1]))
+    eng.set_weights(w)
+    l1, g1, _ = eng.loss_grad(); l2, g2, _ = eng.loss_grad()
+    assert l1 == l2 and np.array_equal(g1, g2)
+    out[pde] = [l1] + g1.tolist()
+    eng.close()
+print("RESULT" + json.dumps(out))
+''' % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
+    res = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_F32_RECOMPUTE=flag), capture_output=True,
+                           text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
+        res[flag] = json.loads(line[0][6:])
+    for pde in ("burgers", "burgers_ide"):
+        a, b = np.array(res["0"][pde]), np.array(res["1"][pde])
+        assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]), pde
+        assert np.max(np.abs(a[1:] - b[1:])) <= 1e-5 * np.max(np.abs(a[1:])), pde
