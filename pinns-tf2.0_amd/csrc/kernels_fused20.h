@@ -67,6 +67,34 @@ template <> struct FusedTraits<double> {
   static __device__ __forceinline__ int out_row(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 };
 
+// Flat-vector layout of a 2 -> 20 x H -> 1 net as COMPILE-TIME constants (the reference layout: W then b per dense
+// layer, utils/neuralnetwork.py:60-77 get_weights / set_weights).  The register-stash kernels take their offsets from
+// here, not from a NetDesc argument: weight addresses become immediate operands and, with the pointers leading the
+// argument list, the first loads of a launch do not wait for a kernel-argument fetch (the leading 14 dwords of the
+// arguments are preloaded into SGPRs: -mllvm -amdgpu-kernarg-preload-count, pinn_native.COMMON_FLAGS).  The launch
+// wrappers check the engine's NetDesc against it (w20_layout_ok).
+struct W20Desc { int off_w[MAX_DENSE]; int off_b[MAX_DENSE]; int n_net; int n_theta; };
+constexpr W20Desc w20_desc(int H, bool lambdas) {
+  W20Desc r{};
+  int off = 0, in = 2;
+  for (int d = 0; d <= H; ++d) {
+    const int out = d < H ? FW : 1;
+    r.off_w[d] = off; off += in * out;
+    r.off_b[d] = off; off += out;
+    in = out;
+  }
+  r.n_net = off;
+  r.n_theta = off + (lambdas ? 2 : 0);
+  return r;
+}
+inline bool w20_layout_ok(const NetDesc& nd, int H, bool lambdas) {
+  const W20Desc w = w20_desc(H, lambdas);
+  if (nd.n_hidden != H || nd.width != FW || nd.n_out != 1 || nd.n_net != w.n_net || nd.n_theta != w.n_theta) return false;
+  for (int d = 0; d <= H; ++d)
+    if (nd.off_w[d] != w.off_w[d] || nd.off_b[d] != w.off_b[d]) return false;
+  return true;
+}
+
 inline bool fused20_supported(const NetDesc& nd) {
   return nd.width == FW && nd.n_out == 1 && nd.n_hidden >= 2;
 }

@@ -147,12 +147,12 @@ __device__ __forceinline__ void preact_adjoint_d(const double a, const double zp
 // ONE_TILE: the launch has at least as many workgroups as tiles: every gradient block is produced exactly once, so
 // it is stored, not accumulated (no LDS read-modify-write), and there is no loop-carried coordinate prefetch.
 template <int PDE, int H, bool ONE_TILE>
-__global__ __launch_bounds__(256) void k_fused20d(NetDesc nd, SetDesc sd, const double* __restrict__ th,
-                                                  const double* __restrict__ xs, const double* __restrict__ ts,
-                                                  const double* __restrict__ tgt, double lbx, double lbt, double sx,
-                                                  double st, double nu, double* __restrict__ part, int R,
-                                                  int n_tiles, const int* __restrict__ row_index,
-                                                  long long* __restrict__ stamps) {
+__global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th, const double* __restrict__ xs,
+                                                  const double* __restrict__ ts, const double* __restrict__ tgt,
+                                                  double* __restrict__ part, const int* __restrict__ row_index, int R,
+                                                  int n_tiles, double lbx, double lbt, double sx, double st, double nu,
+                                                  SetDesc sd, long long* __restrict__ stamps) {
+  constexpr W20Desc nd = w20_desc(H, PDE == 1);      // (pointers + R + n_tiles = the 14 preloaded argument dwords)
   constexpr int NBLK = fused20d_blocks(H);
   constexpr int BLK_H = 5 + (H - 1) * 30;            // first block of dense H
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -490,6 +490,7 @@ inline int fused20d_launch(const NetDesc& nd, const SetDesc& sd, const double* t
                            const double* tgt, double lbx, double lbt, double sx, double st, double nu, double* part,
                            int R, int n_wg, const int* row_index, hipStream_t stream, long long* stamps = nullptr,
                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+  if (!w20_layout_ok(nd, H, PDE == 1)) return (int)hipErrorInvalidValue;
   const size_t lds = fused20d_lds_bytes(H, nd.n_theta);
   static unsigned long long attr_set = 0;
   if (first_call_on_device(attr_set)) {
@@ -502,11 +503,11 @@ inline int fused20d_launch(const NetDesc& nd, const SetDesc& sd, const double* t
   const int n_tiles = sd.n_pad / 64;
   auto* const kern = n_wg >= n_tiles ? k_fused20d<PDE, H, true> : k_fused20d<PDE, H, false>;
   if (ev_start && ev_stop)
-    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd, th,
-                          xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, row_index, stamps);
+    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, th, xs, ts, tgt, part,
+                          row_index, R, n_tiles, lbx, lbt, sx, st, nu, sd, stamps);
   else
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, nd, sd, th, xs, ts, tgt, lbx, lbt,
-                       sx, st, nu, part, R, n_tiles, row_index, stamps);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, th, xs, ts, tgt, part, row_index, R, n_tiles, lbx,
+                       lbt, sx, st, nu, sd, stamps);
   return (int)hipGetLastError();
 }
 

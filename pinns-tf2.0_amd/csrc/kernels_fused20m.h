@@ -234,15 +234,12 @@ __device__ __forceinline__ void gemv_mfma(acc4 (&acc_own)[4], acc4& acc_g4, cons
 #define PINN_STASH_KEEP(d) true
 #endif
 template <int PDE, int H, bool ONE_TILE>
-__global__ PINN_F20M_BOUNDS void k_fused20m(NetDesc nd, SetDesc sd,
-                                                  const float* __restrict__ th,
-                                                  const float* __restrict__ img,
-                                                  const float* __restrict__ xs,
-                                                  const float* __restrict__ ts,
-                                                  const float* __restrict__ tgt, float lbx, float lbt,
-                                                  float sx, float st, float nu,
-                                                  float* __restrict__ part, int R, int n_tiles,
-                                                  long long* __restrict__ stamps) {
+__global__ PINN_F20M_BOUNDS void k_fused20m(const float* __restrict__ th, const float* __restrict__ img,
+                                            const float* __restrict__ xs, const float* __restrict__ ts,
+                                            const float* __restrict__ tgt, float* __restrict__ part, int R,
+                                            int n_tiles, float lbx, float lbt, float sx, float st, float nu,
+                                            SetDesc sd, long long* __restrict__ stamps) {
+  constexpr W20Desc nd = w20_desc(H, PDE == 1);      // (pointers + R + n_tiles = the 14 preloaded argument dwords)
   constexpr int RS4 = 65;
   constexpr int BUFV = FROWS * RS4;                 // v4f elements per exchange buffer
   constexpr int NW = ((H - 1) * WIMG + 1023) / 1024 * 1024;   // floats of weight image (whole rounds of 4 DMA pieces)
@@ -650,6 +647,7 @@ inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th
                            float sx, float st, float nu, float* part, int R, int n_wg,
                            hipStream_t stream, long long* stamps = nullptr, hipEvent_t ev_start = nullptr,
                            hipEvent_t ev_stop = nullptr) {
+  if (!w20_layout_ok(nd, H, PDE == 1)) return (int)hipErrorInvalidValue;
   const size_t lds = fused20m_lds_bytes(H);
   static unsigned long long attr_set = 0;
   if (first_call_on_device(attr_set)) {
@@ -663,11 +661,11 @@ inline int fused20m_launch(const NetDesc& nd, const SetDesc& sd, const float* th
   const int n_tiles = sd.n_pad / 64;
   auto* const kern = n_wg >= n_tiles ? k_fused20m<PDE, H, true> : k_fused20m<PDE, H, false>;
   if (ev_start && ev_stop)      // the events take the kernel's own begin / end timestamps (what a profiler reports)
-    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, nd, sd,
-                          th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, stamps);
+    hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, th, img, xs, ts, tgt, part,
+                          R, n_tiles, lbx, lbt, sx, st, nu, sd, stamps);
   else
-    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, nd, sd, th, img, xs,
-                       ts, tgt, lbx, lbt, sx, st, nu, part, R, n_tiles, stamps);
+    hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, th, img, xs, ts, tgt, part, R, n_tiles, lbx, lbt, sx,
+                       st, nu, sd, stamps);
   return (int)hipGetLastError();
 }
 

@@ -350,6 +350,9 @@ __global__ __launch_bounds__(256) void k_zero_list(ZeroList zl) {
   }
 }
 
+#ifndef LBC_SGB
+#define LBC_SGB 1
+#endif
 constexpr int LBC_THREADS = 1024;  // k_lbc_coef: 16 waves stage the Gram matrices, wave 0 runs the recursion
 constexpr int LBC_ROWS = 4;        // ceil(62 / 16) matrix rows per thread
 constexpr int LBD_THREADS = 1024;  // k_lbc_dots: n = 3021 is three strides of a 1024-thread block
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   double* const sT = sY + M1 * LD;                 // 6 x 64 per-slot vectors: say sya yya sg yg ro
   double* const sC = sT + 6 * 64;                  // cs[64] | cy[64] | {t, cg, apply, will_eval}
   double* const sP = sC + 192;                     // [16][64] partial sums of the update
+  double* const sZ = sP + 16 * 64;                 // 64 zeros: the matrix row of the lanes beyond M1
   CSTAMP(0);
   // ---- every global read of this kernel, issued as ONE round (a dependent round costs 1.5-2 us)
   const bool in_row = lane < M1;
@@ -567,6 +571,10 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     sT[0 * 64 + lane] = d_say; sT[1 * 64 + lane] = d_sya; sT[2 * 64 + lane] = d_yya;
     sT[3 * 64 + lane] = d_sg;  sT[4 * 64 + lane] = d_yg;  sT[5 * 64 + lane] = ro_l;
     if (writer && in_row) ro_out[lane] = ro_l;
+    sZ[lane] = 0.0;
+  }
+  if (wave == 1 && LD > M1 && in_row) {            // pad column of the three matrices (read, times zero, by the recursion)
+    sU[lane * LD + M1] = 0.0; sL[lane * LD + M1] = 0.0; sY[lane * LD + M1] = 0.0;
   }
   lds_barrier();     // LDS-only: must not wait for global stores
   CSTAMP(2);
@@ -608,30 +616,45 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     const int sidx = in_row ? slot : 0;
     const double sg_p = valid ? sT[3 * 64 + sidx] : 0.0, yg_p = valid ? sT[4 * 64 + sidx] : 0.0;
     const double ro_p = valid ? sT[5 * 64 + sidx] : 0.0;
-    const double* __restrict__ rowU = sU + (in_row ? lane : 0) * LD;
-    const double* __restrict__ rowY = sY + (in_row ? lane : 0) * LD;
-    const double* __restrict__ rowL = sL + (in_row ? lane : 0) * LD;
+    const double* __restrict__ rowU = in_row ? sU + lane * LD : sZ;     // lanes >= M1 read a row of zeros
+    const double* __restrict__ rowY = in_row ? sY + lane * LD : sZ;
+    const double* __restrict__ rowL = in_row ? sL + lane * LD : sZ;
     // Both loops run in chunks of 8 steps: a chunk is straight-line code (its 8-16 LDS operands are
     // fetched together, ahead of the dependent broadcast->fma chain) and is skipped as a whole when
-    // it lies beyond len.  Steps in [len, M1) inside the last chunk are harmless: their lanes hold
-    // exact zeros and their matrix columns are zero.
+    // it lies beyond len.  Steps in [len, 64) inside the last chunk are harmless: their lanes hold
+    // exact zeros (lanes >= M1 because their operands are forced to zero) and their matrix columns are zero.
+    // A step is exactly {v_readlane x2 -> v_fma_f64}: NOTHING scalar sits between the broadcast and the fma.  A
+    // select or a branch on the lane index inside the chain costs as much as the broadcast itself
+    // (profiles/ubench/chain_latency.hip: 24.8 -> 48.5 ticks per step; the guarded loops ran at 100 / 76).
     // backward loop (custom_lbfgs.py:130-133): al_i = ro_i s_i.q_i, q_i = -g - sum_{j>i} al_j y_j
     double bacc = ro_p * -sg_p, yq0 = -yg_p;
+    constexpr int NCH = (LBC_MAXSLOTS + 7) / 8;
+    const int top = uni((len + 7) >> 3) - 1;          // last chunk in use (-1: empty history)
+    // Operands: two register sets, alternating; those of chunk c8 - 1 are fetched one pair per step INSIDE the chain
+    // of chunk c8 (a lone wave issues in order: the fetches fill the slots in which the chain waits for its
+    // broadcast; fetched in a block ahead of the chain they cost ~40 ticks per step).  Column indices run to
+    // 8 * NCH - 1 = 63 without a clamp (immediate offsets): beyond M1 they read the pad column (zeroed above), the
+    // first elements of the next row or of the next staged array -- finite values, multiplied by a lane that holds 0.
+    double ub[2][8], yb[2][8];
 #pragma unroll
-    for (int c8 = (LBC_MAXSLOTS + 7) / 8 - 1; c8 >= 0; --c8) {
-      if (8 * c8 < len) {
-        double uu[8], yvv[8];
+    for (int c8 = NCH - 1; c8 >= 0; --c8) {
+      if (c8 <= top) {
+        if (c8 == top) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int ii = 8 * c8 + k, ic = ii < M1 ? ii : M1 - 1;
-          uu[k] = rowU[ic]; yvv[k] = rowY[ic];
+          for (int k = 0; k < 8; ++k) { ub[c8 & 1][k] = rowU[8 * c8 + k]; yb[c8 & 1][k] = rowY[8 * c8 + k]; }
         }
 #pragma unroll
         for (int k = 7; k >= 0; --k) {
-          const int ii = 8 * c8 + k;
-          const double al_i = (ii < M1) ? read_lane(bacc, ii) : 0.0;
-          bacc -= al_i * uu[k];
-          yq0 -= al_i * yvv[k];
+          const double al_i = read_lane(bacc, 8 * c8 + k);
+          bacc -= al_i * ub[c8 & 1][k];
+          yq0 -= al_i * yb[c8 & 1][k];
+          if (c8 > 0) { ub[(c8 - 1) & 1][k] = rowU[8 * (c8 - 1) + k]; yb[(c8 - 1) & 1][k] = rowY[8 * (c8 - 1) + k]; }
+#if LBC_SGB
+          __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // broadcast
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the two fetches sit in the broadcast's hazard slots
+          __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);      // fma, fma
+#endif
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -639,20 +662,25 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     CSTAMP(4);
     // forward loop (:136-139): be_i = ro_i y_i.(Hdiag q_0 + sum_{j<i} cs_j s_j), cs_i = al_i - be_i
     double eacc = al - ro_p * (Hdiag * yq0);
+    double lb[2][8];
+    if (top >= 0) {
 #pragma unroll
-    for (int c8 = 0; c8 < (LBC_MAXSLOTS + 7) / 8; ++c8) {
-      if (8 * c8 < len) {
-        double lv[8];
+      for (int k = 0; k < 8; ++k) lb[0][k] = rowL[k];
+    }
+#pragma unroll
+    for (int c8 = 0; c8 < NCH; ++c8) {
+      if (c8 <= top) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const int ii = 8 * c8 + k, ic = ii < M1 ? ii : M1 - 1;
-          lv[k] = rowL[ic];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int ii = 8 * c8 + k;
-          const double c_i = (ii < M1) ? read_lane(eacc, ii) : 0.0;
-          eacc -= c_i * lv[k];
+          const double c_i = read_lane(eacc, 8 * c8 + k);
+          eacc -= c_i * lb[c8 & 1][k];
+          if (c8 + 1 < NCH) lb[(c8 + 1) & 1][k] = rowL[8 * (c8 + 1) + k];     // (chunk top + 1: finite, never used)
+#if LBC_SGB
+          __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x2, 1, 0);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -704,6 +732,6 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   if (sC[131] != 0.0) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
 }
 
-inline size_t lbc_coef_apply_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64 + 192 + 16 * 64) * 8; }
+inline size_t lbc_coef_apply_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64 + 192 + 16 * 64 + 64) * 8; }
 
 }  // namespace pinn

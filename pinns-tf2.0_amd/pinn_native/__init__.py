@@ -31,7 +31,8 @@ class PinnNativeError(RuntimeError):
     pass
 
 
-COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC",
+                "-mllvm", "-amdgpu-kernarg-preload-count=16"]   # leading argument dwords arrive in SGPRs (no s_load round trip)
 UNITS = [("engine.hip", []), ("fused20d_unit.hip", ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]), ("fused20m_unit.hip", [])]
 
 
@@ -183,7 +184,7 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if _stale():
+    if not os.environ.get("PINN_HIP_LIB") and _stale():     # an explicitly named library (a variant build) is used as it is
         try:
             build()
         except PinnNativeError:
