@@ -172,6 +172,12 @@ struct pinn_ctx {
   // compact (Gram-matrix) mode
   int lb_mode = 1, lb_mode_active = 0, lb_M1 = 0;
   double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
+  // single-GPU fused tail (k_lbc_reduce_dots): partial dot products per 64-column tile of the gradient vector
+  double* lb_pd = nullptr;
+  int lb_pd_cap = 0;                 // doubles allocated
+  bool lb_fuse_ok = false;           // this run may fuse (mode 1, one GPU, <= LBP_MAXTILES tiles, PINN_LBFGS_FUSE != 0)
+  bool lb_fuse_eval = false;         // the evaluation being issued belongs to an L-BFGS iteration: fuse its reduction
+  bool lb_pd_ready = false;          // lb_pd holds the dot products of the latest evaluation
   LbcExtra* lb_ex = nullptr;
 
   // collocation set generated on the device (pinn_lhs_collocation) instead of handed over
@@ -424,6 +430,15 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
                          (real*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 0.0, 0.0, 0.0, (double*)nullptr,
                          c->nd, (float*)nullptr);
     HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if (c->lb_fuse_eval && !af) {   // L-BFGS iteration on one GPU: the dot products ride on the reduction
+    hipLaunchKernelGGL((k_lbc_reduce_dots<real>), rgrid, dim3(RED_THREADS), lbc_reduce_dots_lds_bytes(), c->stream,
+                       (const real*)c->part, n_rows, c->R, c->gl, c->nd.n_theta, c->lb_M1,
+                       (const LbfgsState*)(c->lb_state + c->lb_flip), (const double*)c->lb_gold, (const double*)c->lb_d,
+                       c->lb_S, c->lb_Y, c->lb_pd, c->n_evals, c->d_nonfinite);
+    HIPCHK(hipGetLastError());
+    c->lb_pd_ready = true;
     return 0;
   }
   if (af)
@@ -753,6 +768,7 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
   int rc = is_disc(c) ? disc_ensure(c) : ensure_sets(c);
   if (rc) return rc;
   c->n_evals += 1;
+  if (!c->lb_fuse_eval) c->lb_pd_ready = false;      // any other evaluation overwrites gl: its dot products are not in lb_pd
   hipEvent_t* ev4 = nullptr;
   if (c->timing && c->ev_used < c->ev_cap_evals && (c->ev_seen++ % c->ev_every) == 0)
     ev4 = &c->ev[(size_t)4 * c->ev_used];
@@ -1095,7 +1111,7 @@ int pinn_destroy(pinn_ctx* c) {
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp,
-                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite};
+                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite, c->lb_pd};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
   if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
@@ -1309,10 +1325,32 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   // compact mode needs the two padded Gram matrices in LDS (<= 64 KiB) and one lane per slot
   c->lb_mode_active = (c->lb_mode == 1 && M1 <= LBC_MAXSLOTS) ? 1 : 0;
   if (c->lb_mode_active && lbc_coef_apply_lds_bytes(M1) > 64 * 1024) {
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lbc_coef_apply_lds_bytes(M1)));
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lbc_coef_apply_lds_bytes(M1)));
+    const int lds = (int)lbc_coef_apply_lds_bytes(M1);
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  {
+    // OPT-IN (PINN_LBFGS_FUSE=1, read per run): the two-launch tail is parity-green and measured no faster than the
+    // three-launch one (f64 iteration 54.67 vs 54.54 us, profiles/r03_lbfgs_tail.txt): what k_lbc_dots costs is paid
+    // back by the 240 extra loads per workgroup with which k_lbc_coef_apply sums the partial sets
+    const char* fe = getenv("PINN_LBFGS_FUSE");
+    const bool fuse_env = fe && fe[0] == '1';
+    const int tiles = (c->R + RED_COLS - 1) / RED_COLS;
+    c->lb_fuse_ok = fuse_env && c->lb_mode_active && !c->comm && !c->xg.on && tiles <= LBP_MAXTILES;
+    c->lb_fuse_eval = false; c->lb_pd_ready = false;
+    if (c->lb_fuse_ok) {
+      const int need = tiles * lbc_nd(M1);
+      if (need > c->lb_pd_cap) {
+        if (dev_alloc(&c->lb_pd, (size_t)need * 8)) return PINN_EHIP;
+        c->lb_pd_cap = need;
+      }
+      HIPCHK(hipFuncSetAttribute((const void*)k_lbc_reduce_dots<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lbc_reduce_dots_lds_bytes()));
+      HIPCHK(hipFuncSetAttribute((const void*)k_lbc_reduce_dots<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lbc_reduce_dots_lds_bytes()));
+    }
   }
   if (n_corr > c->lb_cap_corr) {
     if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
@@ -1384,19 +1422,29 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
       LbfgsState* st_in = c->lb_state + c->lb_flip;
       LbfgsState* st_out = c->lb_state + (c->lb_flip ^ 1);
       const size_t mm = (size_t)M1 * M1;
-      hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
-                         c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+      // dot products of this iteration: already formed behind the evaluation's reduction (one partial set per
+      // 64-column tile), or by k_lbc_dots (one set) -- N > 1 ranks, the first iteration after pinn_lbfgs_begin,
+      // an evaluation issued by somebody else in between
+      const double* pd = c->lb_pd;
+      int n_part = (c->R + RED_COLS - 1) / RED_COLS;
+      if (!c->lb_pd_ready) {
+        hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
+                           c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+        pd = c->lb_dots; n_part = 1;
+      }
+      c->lb_pd_ready = false;
       const dim3 agrid((n + 63) / 64);
-#define COEF_APPLY(REAL)                                                                           \
-      hipLaunchKernelGGL((k_lbc_coef_apply<REAL>), agrid, dim3(LBC_THREADS), lsh, c->stream, n, M1,   \
+#define COEF_APPLY(REAL, PARTS)                                                                    \
+      hipLaunchKernelGGL((k_lbc_coef_apply<REAL, PARTS>), agrid, dim3(LBC_THREADS), lsh, c->stream, n, M1,   \
                          c->lb_ncorr, c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun,           \
                          c->lb_max_eval, c->lb_post_pending ? 1 : 0, n, st_in, st_out, c->gl,         \
-                         c->lb_dots, c->lb_SY + c->lb_flip * mm, c->lb_YY + c->lb_flip * mm,          \
+                         pd, n_part, c->lb_SY + c->lb_flip * mm, c->lb_YY + c->lb_flip * mm,          \
                          c->lb_ro + c->lb_flip * M1, c->lb_SY + (c->lb_flip ^ 1) * mm,                \
                          c->lb_YY + (c->lb_flip ^ 1) * mm, c->lb_ro + (c->lb_flip ^ 1) * M1,          \
                          c->lb_log_iter, c->lb_log_loss, c->lb_S, c->lb_Y, c->lb_d, c->lb_gold,       \
                          c->lb_x, c->theta, (REAL*)c->theta_r, c->nd, c->img)
-      if (c->dtype == PINN_F64) COEF_APPLY(double); else COEF_APPLY(float);
+      if (n_part > 1) { if (c->dtype == PINN_F64) COEF_APPLY(double, true); else COEF_APPLY(float, true); }
+      else { if (c->dtype == PINN_F64) COEF_APPLY(double, false); else COEF_APPLY(float, false); }
 #undef COEF_APPLY
       c->lb_post_pending = false;
       c->lb_flip ^= 1;
@@ -1405,7 +1453,9 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     else
       hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
+    c->lb_fuse_eval = c->lb_fuse_ok && c->lb_mode_active;
     int rc = eval_loss_grad(c);
+    c->lb_fuse_eval = false;
     if (rc) return rc;
     if (c->lb_mode_active) { c->lb_post_pending = true; continue; }   // folded into the next k_lbc_coef
     hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
