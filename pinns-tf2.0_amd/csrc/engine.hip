@@ -441,11 +441,20 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
     c->lb_pd_ready = true;
     return 0;
   }
-  if (af)
+  const bool pairs = (c->R & 1) == 0;             // even row pitch: two columns per thread, half the load instructions
+  if (af && pairs)
+    hipLaunchKernelGGL((k_reduce_adam2<real>), rgrid, dim3(RED2_THREADS), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
+                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img, c->n_evals,
+                       c->d_nonfinite);
+  else if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
                        c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img, c->n_evals,
                        c->d_nonfinite);
+  else if (pairs)
+    hipLaunchKernelGGL((k_reduce_rows2<real>), rgrid, dim3(RED2_THREADS), 0, c->stream, (const real*)c->part,
+                       n_rows, c->R, c->gl, c->nd.n_theta, c->n_evals, c->d_nonfinite);
   else
     hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->n_evals, c->d_nonfinite);
@@ -1353,7 +1362,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     }
   }
   if (n_corr > c->lb_cap_corr) {
-    if (dev_alloc(&c->lb_S, (size_t)M1 * n * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * n * 8) ||
+    if (dev_alloc(&c->lb_S, (size_t)M1 * ring_ld((int)n) * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * ring_ld((int)n) * 8) ||
         dev_alloc(&c->lb_ro, (size_t)2 * M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_SY, (size_t)2 * M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)2 * M1 * M1 * 8) ||
         dev_alloc(&c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
@@ -1365,7 +1374,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     static_assert(sizeof(LbcExtra) % 8 == 0, "LbcExtra is cleared as doubles");
     ZeroList zl{};
     auto add = [&](void* p, size_t doubles) { zl.p[zl.count] = (double*)p; zl.n[zl.count] = doubles; zl.count++; };
-    add(c->lb_S, (size_t)M1 * n); add(c->lb_Y, (size_t)M1 * n); add(c->lb_cs, M1); add(c->lb_cy, M1);
+    add(c->lb_S, (size_t)M1 * ring_ld((int)n)); add(c->lb_Y, (size_t)M1 * ring_ld((int)n)); add(c->lb_cs, M1); add(c->lb_cy, M1);
     add(c->lb_SY, (size_t)2 * M1 * M1); add(c->lb_YY, (size_t)2 * M1 * M1); add(c->lb_ro, (size_t)2 * M1);
     add(c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL)); add(c->lb_ex, sizeof(LbcExtra) / 8);
     // the optimiser state starts as {0..., Hdiag = 1}: written by the same launch (no host buffer in flight)

@@ -49,6 +49,50 @@ __device__ __forceinline__ double reduce_column(const real* __restrict__ part, i
   return tot;
 }
 
+// Two adjacent columns per thread (requires an even row pitch R): the same per-column arithmetic as reduce_column --
+// same row slices, same eight accumulators, same combination order, so the sums are bit-identical -- with half the
+// vector-memory instructions per workgroup (16 / 8 bytes per lane for float64 / float32 rows).  The cost of these
+// small kernels' single round of reads is the number of such instructions a CU executes (~20 ticks each).
+// Block = 32 column pairs x 16 row slices = 512 threads.
+constexpr int RED2_THREADS = RED_COLS / 2 * RED_SLICES;
+template <typename real> struct pair_of;
+template <> struct pair_of<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct pair_of<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
+template <typename real>
+__device__ __forceinline__ void reduce_column_pair(const real* __restrict__ part, int n_rows, int R, int c, int q,
+                                                   double (*sh)[RED_COLS], double& t0, double& t1) {
+  typedef typename pair_of<real>::type r2;
+  const int cl = 2 * (threadIdx.x & 31);
+  double a[8][2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a[k][0] = a[k][1] = 0.0;
+  if (c < R) {                                   // R even, c even: c + 1 < R too
+    const real* __restrict__ p = part + c;
+    auto ld = [&](const int r, const int k) {
+      const r2 v = *reinterpret_cast<const r2*>(p + (size_t)r * R);
+      a[k][0] += (double)v.x; a[k][1] += (double)v.y;
+    };
+    int r = q;
+    for (; r + 7 * RED_SLICES < n_rows; r += 8 * RED_SLICES) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ld(r + k * RED_SLICES, k);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+      if (r + k * RED_SLICES < n_rows) ld(r + k * RED_SLICES, k);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    sh[q][cl + j] = ((a[0][j] + a[1][j]) + (a[2][j] + a[3][j])) + ((a[4][j] + a[5][j]) + (a[6][j] + a[7][j]));
+  __syncthreads();
+  t0 = t1 = 0.0;
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < RED_SLICES; ++i) { t0 += sh[i][cl]; t1 += sh[i][cl + 1]; }
+  }
+}
+
 // Non-finite guard (SURVEY 5 "failure detection"; the reference has none: a NaN loss just propagates,
 // utils/custom_lbfgs.py:154).  The thread that owns a loss slot records the number of the first evaluation whose
 // reduced loss part is not finite; nothing else changes, the trajectory stays the reference's.
@@ -101,6 +145,56 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_adam(const real* __restr
   }
 }
 
+template <typename real>
+__global__ __launch_bounds__(RED2_THREADS) void k_reduce_rows2(const real* __restrict__ part, int n_rows, int R,
+                                                               double* __restrict__ gl, int n_theta,
+                                                               unsigned long long eval_no,
+                                                               unsigned long long* __restrict__ nonfinite) {
+  __shared__ double sh[RED_SLICES][RED_COLS];
+  const int c = blockIdx.x * RED_COLS + 2 * (threadIdx.x & 31), q = threadIdx.x >> 5;
+  double g0, g1;
+  reduce_column_pair(part, n_rows, R, c, q, sh, g0, g1);
+  if (q == 0 && c < R) {
+    gl[c] = g0; gl[c + 1] = g1;
+    note_nonfinite(g0, c, n_theta, eval_no, nonfinite); note_nonfinite(g1, c + 1, n_theta, eval_no, nonfinite);
+  }
+}
+
+template <typename real>
+__global__ __launch_bounds__(RED2_THREADS) void k_reduce_adam2(const real* __restrict__ part, int n_rows, int R,
+                                                               double* __restrict__ gl, int n,
+                                                               double* __restrict__ theta, real* __restrict__ theta_r,
+                                                               double* __restrict__ m, double* __restrict__ v,
+                                                               double alpha, double b1, double b2, double eps,
+                                                               double* __restrict__ loss3, NetDesc nd,
+                                                               float* __restrict__ img, unsigned long long eval_no,
+                                                               unsigned long long* __restrict__ nonfinite) {
+  __shared__ double sh[RED_SLICES][RED_COLS];
+  const int c0 = blockIdx.x * RED_COLS + 2 * (threadIdx.x & 31), q = threadIdx.x >> 5;
+  double gp[2];
+  reduce_column_pair(part, n_rows, R, c0, q, sh, gp[0], gp[1]);
+  if (q != 0 || c0 >= R) return;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                   // same arithmetic as k_reduce_adam, column by column
+    const int c = c0 + j;
+    const double g = gp[j];
+    gl[c] = g;
+    note_nonfinite(g, c, n, eval_no, nonfinite);
+    if (c < n) {
+      const double mi = m[c] + (1.0 - b1) * (g - m[c]);
+      const double vi = v[c] + (1.0 - b2) * (g * g - v[c]);
+      m[c] = mi;
+      v[c] = vi;
+      const double t = theta[c] - alpha * mi / (sqrt(vi) + eps);
+      theta[c] = t;
+      theta_r[c] = (real)t;
+      pack_store_any(nd, img, c, (float)t);
+    } else if (loss3 && c < n + 3) {
+      loss3[c - n] = g;
+    }
+  }
+}
+
 // TF-2.0 ResourceApplyAdam (reference call site
 // utils/neuralnetwork.py:114): m += (1-b1)(g-m); v += (1-b2)(g^2-v);
 // theta -= alpha*m/(sqrt(v)+eps), alpha = lr*sqrt(1-b2^t)/(1-b1^t) computed by the host.
@@ -134,6 +228,9 @@ __global__ void k_cast_weights(int n, const double* __restrict__ theta, real* __
 // ---------------------------------------------------------------------------------------------
 // L-BFGS (utils/custom_lbfgs.py:39-236), one 1024-thread workgroup, float64.
 // ---------------------------------------------------------------------------------------------
+// row stride (doubles) of the two history rings: even, so that a row starts 16-byte aligned (pair loads in k_lbc_dots)
+__host__ __device__ inline size_t ring_ld(int n) { return ((size_t)n + 1) & ~(size_t)1; }
+
 struct LbfgsState {
   int n_iter;        // state.nIter
   int func_eval;     // currentFuncEval
@@ -197,8 +294,8 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
       if (hist_len == n_corr) { slot = head; head = (head + 1) % n_corr; }
       else { slot = (head + hist_len) % n_corr; hist_len += 1; }
       for (int i = tid; i < n; i += LB_THREADS) {
-        Sh[(size_t)slot * n + i] = d[i] * t_prev;
-        Yh[(size_t)slot * n + i] = g[i] - g_old[i];
+        Sh[(size_t)slot * ring_ld(n) + i] = d[i] * t_prev;
+        Yh[(size_t)slot * ring_ld(n) + i] = g[i] - g_old[i];
       }
       if (tid == 0) ro[slot] = 1.0 / ys;               // 1/dot(old_stps[i], old_dirs[i]) (:121-123)
       Hdiag = ys / yy;
@@ -210,10 +307,10 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
     for (int li = hist_len - 1; li >= 0; --li) {
       const int slot = (head + li) % n_corr;
       double p = 0;
-      for (int i = tid; i < n; i += LB_THREADS) p += Sh[(size_t)slot * n + i] * q[i];
+      for (int i = tid; i < n; i += LB_THREADS) p += Sh[(size_t)slot * ring_ld(n) + i] * q[i];
       const double a = block_sum(p, sh) * ro[slot];
       if (tid == 0) al[slot] = a;
-      for (int i = tid; i < n; i += LB_THREADS) q[i] -= a * Yh[(size_t)slot * n + i];
+      for (int i = tid; i < n; i += LB_THREADS) q[i] -= a * Yh[(size_t)slot * ring_ld(n) + i];
       __syncthreads();
     }
     for (int i = tid; i < n; i += LB_THREADS) q[i] *= Hdiag;          // r = q*Hdiag
@@ -221,10 +318,10 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_step(
     for (int li = 0; li < hist_len; ++li) {
       const int slot = (head + li) % n_corr;
       double p = 0;
-      for (int i = tid; i < n; i += LB_THREADS) p += Yh[(size_t)slot * n + i] * q[i];
+      for (int i = tid; i < n; i += LB_THREADS) p += Yh[(size_t)slot * ring_ld(n) + i] * q[i];
       const double be = block_sum(p, sh) * ro[slot];
       const double co = al[slot] - be;
-      for (int i = tid; i < n; i += LB_THREADS) q[i] += co * Sh[(size_t)slot * n + i];
+      for (int i = tid; i < n; i += LB_THREADS) q[i] += co * Sh[(size_t)slot * ring_ld(n) + i];
       __syncthreads();
     }
     for (int i = tid; i < n; i += LB_THREADS) d[i] = q[i];
@@ -385,18 +482,33 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
     const double* __restrict__ g_old, const double* __restrict__ d, double* __restrict__ Sh,
     double* __restrict__ Yh, double* __restrict__ dots) {
   __shared__ double sh[LBD_THREADS / 64][8];
-  constexpr int NS = 4;                           // strides of LBD_THREADS covered (n <= 4096 fast path)
+  // Thread t owns the element PAIRS {2t, 2t+1} + 2048 u, u < NS: every global access is 16 bytes per lane (the cost of
+  // this kernel's one round of reads is the number of vector-memory instructions per CU, ~20 ticks each: 10 per wave
+  // instead of 15 with one element per lane and three strides); ring rows are ring_ld(n) apart, so every pair is
+  // 16-byte aligned.
+  constexpr int NS = 2;                           // pair strides of 2 x LBD_THREADS covered (n <= 4096 fast path)
+  typedef double d2 __attribute__((ext_vector_type(2)));
   const int a = blockIdx.x, tid = threadIdx.x;
-  // one round of global reads: state + this thread's slice of g, g_old, d and of history row a
   const int done0 = st->done, head = st->hist_head, len = st->hist_len, n_it = st->n_iter;
   const double t = st->t;
-  double gv[NS], gov[NS], dv[NS], sav[NS], yav[NS];
+  d2 gv[NS], gov[NS], dv[NS], sav[NS], yav[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    const int i = tid + u * LBD_THREADS;
-    const bool ok = i < n;
-    gv[u] = ok ? g[i] : 0.0; gov[u] = ok ? g_old[i] : 0.0; dv[u] = ok ? d[i] : 0.0;
-    sav[u] = ok ? Sh[(size_t)a * n + i] : 0.0; yav[u] = ok ? Yh[(size_t)a * n + i] : 0.0;
+    const int i = 2 * tid + u * 2 * LBD_THREADS;
+    const d2 z = {0.0, 0.0};
+    gv[u] = gov[u] = dv[u] = sav[u] = yav[u] = z;
+    if (i + 1 < n) {
+      gv[u] = *reinterpret_cast<const d2*>(g + i); gov[u] = *reinterpret_cast<const d2*>(g_old + i);
+      dv[u] = *reinterpret_cast<const d2*>(d + i);
+      sav[u] = *reinterpret_cast<const d2*>(Sh + (size_t)a * ring_ld(n) + i);
+      yav[u] = *reinterpret_cast<const d2*>(Yh + (size_t)a * ring_ld(n) + i);
+    } else if (i < n) {
+      gv[u].x = g[i]; gov[u].x = g_old[i]; dv[u].x = d[i]; sav[u].x = Sh[(size_t)a * ring_ld(n) + i]; yav[u].x = Yh[(size_t)a * ring_ld(n) + i];
+      if (i + 1 < n) {
+        gv[u].y = g[i + 1]; gov[u].y = g_old[i + 1]; dv[u].y = d[i + 1];
+        sav[u].y = Sh[(size_t)a * ring_ld(n) + i + 1]; yav[u].y = Yh[(size_t)a * ring_ld(n) + i + 1];
+      }
+    }
   }
   if (done0) return;
   const bool first = (n_it == 0);
@@ -404,28 +516,23 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
   int pos = a - head; if (pos < 0) pos += M1;
   if (a == c) {
     double v[7] = {0, 0, 0, 0, 0, 0, 0};          // ys yy sg yg gg ga sa
-#pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const int i = tid + u * LBD_THREADS;
+    auto one = [&](const int i, const double gi, const double go, const double di) {
       if (i < n) {
-        const double gi = gv[u];
         v[4] += gi * gi; v[5] += fabs(gi);
         if (!first) {
-          const double y = gi - gov[u], s = dv[u] * t;
-          Sh[(size_t)c * n + i] = s; Yh[(size_t)c * n + i] = y;
+          const double y = gi - go, s = di * t;
+          Sh[(size_t)c * ring_ld(n) + i] = s; Yh[(size_t)c * ring_ld(n) + i] = y;
           v[0] += y * s; v[1] += y * y; v[2] += s * gi; v[3] += y * gi; v[6] += fabs(s);
         }
       }
+    };
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = 2 * tid + u * 2 * LBD_THREADS;
+      one(i, gv[u].x, gov[u].x, dv[u].x);
+      one(i + 1, gv[u].y, gov[u].y, dv[u].y);
     }
-    for (int i = tid + NS * LBD_THREADS; i < n; i += LBD_THREADS) {      // n > 4096: plain loop
-      const double gi = g[i];
-      v[4] += gi * gi; v[5] += fabs(gi);
-      if (!first) {
-        const double y = gi - g_old[i], s = d[i] * t;
-        Sh[(size_t)c * n + i] = s; Yh[(size_t)c * n + i] = y;
-        v[0] += y * s; v[1] += y * y; v[2] += s * gi; v[3] += y * gi; v[6] += fabs(s);
-      }
-    }
+    for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS) one(i, g[i], g_old[i], d[i]);   // n > 4096: plain loop
     block_sums(v, sh);
     if (tid == 0) {
       dots[5 * M1 + 0] = v[0]; dots[5 * M1 + 1] = v[1]; dots[5 * M1 + 2] = v[4]; dots[5 * M1 + 3] = v[5];
@@ -434,17 +541,17 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
     }
   } else if (pos < len) {
     double v[5] = {0, 0, 0, 0, 0};                // say sya yya sg yg
+    auto one = [&](const double gi, const double go, const double di, const double sa, const double ya) {
+      const double yc = gi - go, sc = di * t;
+      v[0] += sa * yc; v[1] += sc * ya; v[2] += ya * yc; v[3] += sa * gi; v[4] += ya * gi;
+    };
 #pragma unroll
-    for (int u = 0; u < NS; ++u) {
-      const double gi = gv[u], sa = sav[u], ya = yav[u];
-      const double yc = gi - gov[u], sc = dv[u] * t;
-      v[0] += sa * yc; v[1] += sc * ya; v[2] += ya * yc; v[3] += sa * gi; v[4] += ya * gi;
+    for (int u = 0; u < NS; ++u) {                // (elements beyond n hold zeros: no guard needed)
+      one(gv[u].x, gov[u].x, dv[u].x, sav[u].x, yav[u].x);
+      one(gv[u].y, gov[u].y, dv[u].y, sav[u].y, yav[u].y);
     }
-    for (int i = tid + NS * LBD_THREADS; i < n; i += LBD_THREADS) {
-      const double gi = g[i], sa = Sh[(size_t)a * n + i], ya = Yh[(size_t)a * n + i];
-      const double yc = gi - g_old[i], sc = d[i] * t;
-      v[0] += sa * yc; v[1] += sc * ya; v[2] += ya * yc; v[3] += sa * gi; v[4] += ya * gi;
-    }
+    for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS)
+      one(g[i], g_old[i], d[i], Sh[(size_t)a * ring_ld(n) + i], Yh[(size_t)a * ring_ld(n) + i]);
     block_sums(v, sh);
     if (tid == 0) {
       dots[a] = v[0]; dots[M1 + a] = v[1]; dots[2 * M1 + a] = v[2];
@@ -504,8 +611,8 @@ __global__ __launch_bounds__(RED_THREADS) void k_lbc_reduce_dots(
   for (int u = 0; u < 4; ++u) {
     const int a = q + 16 * u;
     const bool ok = el && a < M1;
-    sv[u] = ok ? Sh[(size_t)a * n + c] : 0.0;
-    yv[u] = ok ? Yh[(size_t)a * n + c] : 0.0;
+    sv[u] = ok ? Sh[(size_t)a * ring_ld(n) + c] : 0.0;
+    yv[u] = ok ? Yh[(size_t)a * ring_ld(n) + c] : 0.0;
   }
   const double g = reduce_column(part, n_rows, R, c, q, sh);
   if (q == 0 && c < R) { gl[c] = g; note_nonfinite(g, c, n, eval_no, nonfinite); }
@@ -516,7 +623,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_lbc_reduce_dots(
     const double gi = el ? g : 0.0;
     const double yc = (first || !el) ? 0.0 : gi - go, sc = (first || !el) ? 0.0 : dv * t;
     vG[lane] = gi; vY[lane] = yc; vS[lane] = sc;
-    if (!first && el) { Sh[(size_t)cs * n + c] = sc; Yh[(size_t)cs * n + c] = yc; }
+    if (!first && el) { Sh[(size_t)cs * ring_ld(n) + c] = sc; Yh[(size_t)cs * ring_ld(n) + c] = yc; }
   }
   __syncthreads();
 #pragma unroll
@@ -635,6 +742,8 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   }
   const double ro_l0 = in_row ? ro_in[lane] : 0.0;
   const double f_new = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
+  // (Tried: both Gram matrices read flat, 16 bytes per lane -- 42 load instructions per workgroup instead of 128 --
+  //  with the staging done element by element: 53.81 vs 53.59 us per iteration, no gain, reverted.)
   double ra[LBC_ROWS], rb[LBC_ROWS];
 #pragma unroll
   for (int u = 0; u < LBC_ROWS; ++u) {
@@ -656,8 +765,8 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     for (int u = 0; u < 4; ++u) {
       const int sl = wave + 16 * u;
       const bool ok = iok && sl < M1;
-      yv[u] = ok ? Yh[(size_t)sl * n + i] : 0.0;
-      sv[u] = ok ? Sh[(size_t)sl * n + i] : 0.0;
+      yv[u] = ok ? Yh[(size_t)sl * ring_ld(n) + i] : 0.0;
+      sv[u] = ok ? Sh[(size_t)sl * ring_ld(n) + i] : 0.0;
     }
   };
   if (wave == 0) fetch_history();
