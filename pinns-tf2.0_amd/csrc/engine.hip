@@ -441,20 +441,11 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
     c->lb_pd_ready = true;
     return 0;
   }
-  const bool pairs = (c->R & 1) == 0;             // even row pitch: two columns per thread, half the load instructions
-  if (af && pairs)
-    hipLaunchKernelGGL((k_reduce_adam2<real>), rgrid, dim3(RED2_THREADS), 0, c->stream, (const real*)c->part,
-                       n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
-                       c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img, c->n_evals,
-                       c->d_nonfinite);
-  else if (af)
+  if (af)
     hipLaunchKernelGGL((k_reduce_adam<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->theta, (real*)c->theta_r, c->adam_m,
                        c->adam_v, af->alpha, c->b1, c->b2, c->eps, af->loss3, c->nd, c->img, c->n_evals,
                        c->d_nonfinite);
-  else if (pairs)
-    hipLaunchKernelGGL((k_reduce_rows2<real>), rgrid, dim3(RED2_THREADS), 0, c->stream, (const real*)c->part,
-                       n_rows, c->R, c->gl, c->nd.n_theta, c->n_evals, c->d_nonfinite);
   else
     hipLaunchKernelGGL((k_reduce_rows<real>), rgrid, dim3(RED_THREADS), 0, c->stream, (const real*)c->part,
                        n_rows, c->R, c->gl, c->nd.n_theta, c->n_evals, c->d_nonfinite);

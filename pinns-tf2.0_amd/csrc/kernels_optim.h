@@ -15,7 +15,8 @@ namespace pinn {
 constexpr int RED_COLS = 64;
 constexpr int RED_SLICES = 16;
 constexpr int RED_THREADS = RED_COLS * RED_SLICES;   // (measured: 8 / 16 / 32 columns per workgroup, i.e. 8x / 4x / 2x the
-                                                     //  workgroups, are no faster: f64 Adam step 41.9 / 40.9 / 40.6 vs 40.9 us)
+                                                     //  workgroups, are no faster: f64 Adam step 41.9 / 40.9 / 40.6 vs 40.9 us; neither are two columns per thread
+                                                     //  on an even row pitch, 512 threads, bit-identical sums: 41.3 vs 40.8 us, f32 29.3 vs 28.3)
 
 template <typename real>
 __device__ __forceinline__ double reduce_column(const real* __restrict__ part, int n_rows, int R,
@@ -47,50 +48,6 @@ __device__ __forceinline__ double reduce_column(const real* __restrict__ part, i
     for (int i = 0; i < RED_SLICES; ++i) tot += sh[i][cl];
   }
   return tot;
-}
-
-// Two adjacent columns per thread (requires an even row pitch R): the same per-column arithmetic as reduce_column --
-// same row slices, same eight accumulators, same combination order, so the sums are bit-identical -- with half the
-// vector-memory instructions per workgroup (16 / 8 bytes per lane for float64 / float32 rows).  The cost of these
-// small kernels' single round of reads is the number of such instructions a CU executes (~20 ticks each).
-// Block = 32 column pairs x 16 row slices = 512 threads.
-constexpr int RED2_THREADS = RED_COLS / 2 * RED_SLICES;
-template <typename real> struct pair_of;
-template <> struct pair_of<float> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct pair_of<double> { typedef double type __attribute__((ext_vector_type(2))); };
-
-template <typename real>
-__device__ __forceinline__ void reduce_column_pair(const real* __restrict__ part, int n_rows, int R, int c, int q,
-                                                   double (*sh)[RED_COLS], double& t0, double& t1) {
-  typedef typename pair_of<real>::type r2;
-  const int cl = 2 * (threadIdx.x & 31);
-  double a[8][2];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) a[k][0] = a[k][1] = 0.0;
-  if (c < R) {                                   // R even, c even: c + 1 < R too
-    const real* __restrict__ p = part + c;
-    auto ld = [&](const int r, const int k) {
-      const r2 v = *reinterpret_cast<const r2*>(p + (size_t)r * R);
-      a[k][0] += (double)v.x; a[k][1] += (double)v.y;
-    };
-    int r = q;
-    for (; r + 7 * RED_SLICES < n_rows; r += 8 * RED_SLICES) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) ld(r + k * RED_SLICES, k);
-    }
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-      if (r + k * RED_SLICES < n_rows) ld(r + k * RED_SLICES, k);
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-    sh[q][cl + j] = ((a[0][j] + a[1][j]) + (a[2][j] + a[3][j])) + ((a[4][j] + a[5][j]) + (a[6][j] + a[7][j]));
-  __syncthreads();
-  t0 = t1 = 0.0;
-  if (q == 0) {
-#pragma unroll
-    for (int i = 0; i < RED_SLICES; ++i) { t0 += sh[i][cl]; t1 += sh[i][cl + 1]; }
-  }
 }
 
 // Non-finite guard (SURVEY 5 "failure detection"; the reference has none: a NaN loss just propagates,
@@ -142,56 +99,6 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_adam(const real* __restr
     pack_store_any(nd, img, c, (float)t);
   } else if (loss3 && c < n + 3) {
     loss3[c - n] = g;
-  }
-}
-
-template <typename real>
-__global__ __launch_bounds__(RED2_THREADS) void k_reduce_rows2(const real* __restrict__ part, int n_rows, int R,
-                                                               double* __restrict__ gl, int n_theta,
-                                                               unsigned long long eval_no,
-                                                               unsigned long long* __restrict__ nonfinite) {
-  __shared__ double sh[RED_SLICES][RED_COLS];
-  const int c = blockIdx.x * RED_COLS + 2 * (threadIdx.x & 31), q = threadIdx.x >> 5;
-  double g0, g1;
-  reduce_column_pair(part, n_rows, R, c, q, sh, g0, g1);
-  if (q == 0 && c < R) {
-    gl[c] = g0; gl[c + 1] = g1;
-    note_nonfinite(g0, c, n_theta, eval_no, nonfinite); note_nonfinite(g1, c + 1, n_theta, eval_no, nonfinite);
-  }
-}
-
-template <typename real>
-__global__ __launch_bounds__(RED2_THREADS) void k_reduce_adam2(const real* __restrict__ part, int n_rows, int R,
-                                                               double* __restrict__ gl, int n,
-                                                               double* __restrict__ theta, real* __restrict__ theta_r,
-                                                               double* __restrict__ m, double* __restrict__ v,
-                                                               double alpha, double b1, double b2, double eps,
-                                                               double* __restrict__ loss3, NetDesc nd,
-                                                               float* __restrict__ img, unsigned long long eval_no,
-                                                               unsigned long long* __restrict__ nonfinite) {
-  __shared__ double sh[RED_SLICES][RED_COLS];
-  const int c0 = blockIdx.x * RED_COLS + 2 * (threadIdx.x & 31), q = threadIdx.x >> 5;
-  double gp[2];
-  reduce_column_pair(part, n_rows, R, c0, q, sh, gp[0], gp[1]);
-  if (q != 0 || c0 >= R) return;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {                   // same arithmetic as k_reduce_adam, column by column
-    const int c = c0 + j;
-    const double g = gp[j];
-    gl[c] = g;
-    note_nonfinite(g, c, n, eval_no, nonfinite);
-    if (c < n) {
-      const double mi = m[c] + (1.0 - b1) * (g - m[c]);
-      const double vi = v[c] + (1.0 - b2) * (g * g - v[c]);
-      m[c] = mi;
-      v[c] = vi;
-      const double t = theta[c] - alpha * mi / (sqrt(vi) + eps);
-      theta[c] = t;
-      theta_r[c] = (real)t;
-      pack_store_any(nd, img, c, (float)t);
-    } else if (loss3 && c < n + 3) {
-      loss3[c - n] = g;
-    }
   }
 }
 
