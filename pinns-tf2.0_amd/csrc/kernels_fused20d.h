@@ -151,8 +151,12 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
                                                   const double* __restrict__ ts, const double* __restrict__ tgt,
                                                   double* __restrict__ part, const int* __restrict__ row_index, int R,
                                                   int n_tiles, double lbx, double lbt, double sx, double st, double nu,
-                                                  SetDesc sd, long long* __restrict__ stamps) {
-  constexpr W20Desc nd = w20_desc(H, PDE == 1);      // (pointers + R + n_tiles = the 14 preloaded argument dwords)
+                                                  SetDesc sd, long long* __restrict__ stamps, W20Desc nd_arg) {
+  // weight offsets: compile-time constants in the one-tile variant (immediate operands; Adam step 41.9 -> 40.8 us with
+  // the preloaded pointers); the tile-loop variant keeps them in SGPRs -- with immediates its schedule came out 9 %
+  // slower (N_f = 10^6: 2104 vs 1930 us per step, same box)
+  constexpr W20Desc nd_const = w20_desc(H, PDE == 1);
+  const W20Desc nd = ONE_TILE ? nd_const : nd_arg;
   constexpr int NBLK = fused20d_blocks(H);
   constexpr int BLK_H = 5 + (H - 1) * 30;            // first block of dense H
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -504,10 +508,10 @@ inline int fused20d_launch(const NetDesc& nd, const SetDesc& sd, const double* t
   auto* const kern = n_wg >= n_tiles ? k_fused20d<PDE, H, true> : k_fused20d<PDE, H, false>;
   if (ev_start && ev_stop)
     hipExtLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, ev_start, ev_stop, 0, th, xs, ts, tgt, part,
-                          row_index, R, n_tiles, lbx, lbt, sx, st, nu, sd, stamps);
+                          row_index, R, n_tiles, lbx, lbt, sx, st, nu, sd, stamps, w20_desc(H, PDE == 1));
   else
     hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, stream, th, xs, ts, tgt, part, row_index, R, n_tiles, lbx,
-                       lbt, sx, st, nu, sd, stamps);
+                       lbt, sx, st, nu, sd, stamps, w20_desc(H, PDE == 1));
   return (int)hipGetLastError();
 }
 

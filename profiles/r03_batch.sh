@@ -1,5 +1,5 @@
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; rm -f gpurun_out/parity_measured.jsonl
-(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15) > gpurun_out/r03_pytest_gpu.log
+(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -vE "^(RCCL|HIP|ROCm|Hostname|Librccl)" | tail -15) > gpurun_out/r03_pytest_gpu.log
 timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_steps20.json 2> gpurun_out/r03_bench_steps20.err
 timeout 300 python bench.py > gpurun_out/r03_bench_default.json 2> gpurun_out/r03_bench_default.err
 cd /tmp; export TMPDIR=/tmp
