@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   // -------------------------------------------------------------------- one gradient row per workgroup
   {
     // row_index[e]: flat parameter index of entry e of the block list (-1: padding), built once on the host;
-    // fetched first so that its (cold) latency hides under the wave sums and the two barriers
+    // fetched first so that its (cold) latency hides under the wave sums and the two barriers  (it does: prefetching
+    // the table into LDS with the weights' DMA changed nothing -- Adam step 40.79 vs 40.81 us, same box)
     constexpr int NE = NBLK * 16, NIT = (NE + 255) / 256;
     int idx[NIT];
 #pragma unroll
