@@ -179,3 +179,35 @@ def test_register_stash_kernels_at_other_depths(dtype, pde_kind, H, n_pts):
     l1, g1, _ = eng2.loss_grad()
     assert abs(lw - l1) <= tl * 10 * abs(l1) and rel(gw, g1) <= tg * 10
     eng.close(); eng2.close()
+
+
+@pytest.mark.parametrize("n_corr", [1, 3, 7, 8, 15, 16, 51, 61])
+def test_compact_lbfgs_follows_the_reference_order_kernel_at_any_history_size(n_corr):
+    """k_lbc_coef_apply (mode 1) against k_lbfgs_step (mode 0, the reference's operation order) for ring sizes M1 = n_corr
+    + 1 that are odd and even (the LDS matrices then carry a pad column, which the unguarded recursion reads), smaller and
+    larger than one 8-step chunk, with the ring wrapping (60 iterations): same losses to rounding while the iterates are
+    close, same log length, float64"""
+    import pinn_native
+    from oracle import init
+    rs = np.random.RandomState(11)
+    layers = [2] + [20] * 4 + [1]
+    pts = lambda n: np.column_stack([rs.uniform(LB[0], UB[0], n), rs.uniform(LB[1], UB[1], n)])
+    X_f, X_u = pts(2000), pts(64)
+    u = -np.sin(np.pi * X_u[:, 0:1])
+    out = {}
+    for mode in (0, 1):
+        eng = pinn_native.Engine(layers, LB, UB, pde="burgers", dtype="f64")
+        eng.set_collocation(X_f); eng.set_data(X_u, u); eng.set_pde_params(NU); eng.set_weights(init.glorot_flat(layers))
+        eng.lbfgs_set_mode(mode)
+        eng.lbfgs_begin(60, 0.8, n_corr, float(np.finfo(float).eps))
+        it, ll, done = [], [], 0
+        while not done:
+            a, b, done = eng.lbfgs_run(13)
+            it += a.tolist(); ll += b.tolist()
+        out[mode] = (np.array(it), np.array(ll), done, eng.get_weights())
+        eng.close()
+    assert out[0][2] == out[1][2] and np.array_equal(out[0][0], out[1][0])
+    dev = np.abs(out[0][1] - out[1][1]) / np.abs(out[0][1])
+    assert np.all(np.isfinite(out[1][1])) and np.all(np.isfinite(out[1][3]))
+    assert dev[:15].max() < 1e-9, dev[:15].max()
+    assert dev.max() < 1e-3, dev.max()
