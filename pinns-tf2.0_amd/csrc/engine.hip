@@ -1356,7 +1356,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     if (dev_alloc(&c->lb_S, (size_t)M1 * ring_ld((int)n) * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * ring_ld((int)n) * 8) ||
         dev_alloc(&c->lb_ro, (size_t)2 * M1 * 8) || dev_alloc(&c->lb_al, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_SY, (size_t)2 * M1 * M1 * 8) || dev_alloc(&c->lb_YY, (size_t)2 * M1 * M1 * 8) ||
-        dev_alloc(&c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
+        dev_alloc(&c->lb_dots, (size_t)2 * (5 * M1 + LBC_NSCAL) * 8) || dev_alloc(&c->lb_cs, (size_t)M1 * 8) ||
         dev_alloc(&c->lb_cy, (size_t)M1 * 8) || dev_alloc(&c->lb_ex, sizeof(LbcExtra)))
       return PINN_EHIP;
     c->lb_cap_corr = n_corr;
@@ -1367,7 +1367,7 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     auto add = [&](void* p, size_t doubles) { zl.p[zl.count] = (double*)p; zl.n[zl.count] = doubles; zl.count++; };
     add(c->lb_S, (size_t)M1 * ring_ld((int)n)); add(c->lb_Y, (size_t)M1 * ring_ld((int)n)); add(c->lb_cs, M1); add(c->lb_cy, M1);
     add(c->lb_SY, (size_t)2 * M1 * M1); add(c->lb_YY, (size_t)2 * M1 * M1); add(c->lb_ro, (size_t)2 * M1);
-    add(c->lb_dots, (size_t)(5 * M1 + LBC_NSCAL)); add(c->lb_ex, sizeof(LbcExtra) / 8);
+    add(c->lb_dots, (size_t)2 * (5 * M1 + LBC_NSCAL)); add(c->lb_ex, sizeof(LbcExtra) / 8);
     // the optimiser state starts as {0..., Hdiag = 1}: written by the same launch (no host buffer in flight)
     static_assert(sizeof(LbfgsState) % 8 == 0 && offsetof(LbfgsState, Hdiag) % 8 == 0, "LbfgsState is initialised as doubles");
     zl.state = (double*)c->lb_state; zl.state_doubles = (int)(sizeof(LbfgsState) / 8);
@@ -1423,14 +1423,22 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
       LbfgsState* st_out = c->lb_state + (c->lb_flip ^ 1);
       const size_t mm = (size_t)M1 * M1;
       // dot products of this iteration: already formed behind the evaluation's reduction (one partial set per
-      // 64-column tile), or by k_lbc_dots (one set) -- N > 1 ranks, the first iteration after pinn_lbfgs_begin,
+      // 64-column tile; opt-in), or by k_lbc_dots (two half sets, one when n > 4096) -- also N > 1 ranks, the first iteration after pinn_lbfgs_begin,
       // an evaluation issued by somebody else in between
       const double* pd = c->lb_pd;
       int n_part = (c->R + RED_COLS - 1) / RED_COLS;
-      if (!c->lb_pd_ready) {
-        hipLaunchKernelGGL(k_lbc_dots, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
-                           c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
-        pd = c->lb_dots; n_part = 1;
+      const bool from_tiles = c->lb_pd_ready;
+      if (!from_tiles) {
+        if (n <= 2 * 2 * LBD_THREADS) {                 // two workgroups per ring slot, one pair stride each
+          hipLaunchKernelGGL(k_lbc_dots<2>, dim3(M1, 2), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
+                             c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+          n_part = 2;
+        } else {
+          hipLaunchKernelGGL(k_lbc_dots<1>, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
+                             c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+          n_part = 1;
+        }
+        pd = c->lb_dots;
       }
       c->lb_pd_ready = false;
       const dim3 agrid((n + 63) / 64);
@@ -1443,7 +1451,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
                          c->lb_YY + (c->lb_flip ^ 1) * mm, c->lb_ro + (c->lb_flip ^ 1) * M1,          \
                          c->lb_log_iter, c->lb_log_loss, c->lb_S, c->lb_Y, c->lb_d, c->lb_gold,       \
                          c->lb_x, c->theta, (REAL*)c->theta_r, c->nd, c->img)
-      if (n_part > 1) { if (c->dtype == PINN_F64) COEF_APPLY(double, true); else COEF_APPLY(float, true); }
+      if (from_tiles) { if (c->dtype == PINN_F64) COEF_APPLY(double, true); else COEF_APPLY(float, true); }
       else { if (c->dtype == PINN_F64) COEF_APPLY(double, false); else COEF_APPLY(float, false); }
 #undef COEF_APPLY
       c->lb_post_pending = false;

@@ -384,16 +384,21 @@ __device__ __forceinline__ void block_sums(double (&v)[NV], double (*sh)[8]) {
 
 // dots layout: [0,M1) s_a.y_c | [M1,2M1) s_c.y_a | [2M1,3M1) y_a.y_c | [3M1,4M1) s_a.g |
 //              [4M1,5M1) y_a.g | 5M1+0 y_c.s_c | +1 y_c.y_c | +2 g.g | +3 |g|_1 | +4 |t d|_1
+// HALVES = 2 (n <= 4096): grid (M1, 2), workgroup (a, h) covers the pair stride h only and writes the partial set h
+// (dots + h * (5 M1 + 5)); k_lbc_coef_apply adds the two sets.  Half the loads per CU again (5 per wave).
+template <int HALVES>
 __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
     int n, int M1, const LbfgsState* __restrict__ st, const double* __restrict__ g,
     const double* __restrict__ g_old, const double* __restrict__ d, double* __restrict__ Sh,
-    double* __restrict__ Yh, double* __restrict__ dots) {
+    double* __restrict__ Yh, double* __restrict__ dots_all) {
   __shared__ double sh[LBD_THREADS / 64][8];
+  double* __restrict__ dots = dots_all + (HALVES == 2 ? blockIdx.y * (5 * M1 + LBC_NSCAL) : 0);
+  const int u0 = HALVES == 2 ? (int)blockIdx.y : 0;
   // Thread t owns the element PAIRS {2t, 2t+1} + 2048 u, u < NS: every global access is 16 bytes per lane (the cost of
   // this kernel's one round of reads is the number of vector-memory instructions per CU, ~20 ticks each: 10 per wave
   // instead of 15 with one element per lane and three strides); ring rows are ring_ld(n) apart, so every pair is
   // 16-byte aligned.
-  constexpr int NS = 2;                           // pair strides of 2 x LBD_THREADS covered (n <= 4096 fast path)
+  constexpr int NS = HALVES == 2 ? 1 : 2;         // pair strides of 2 x LBD_THREADS covered by this workgroup (n <= 4096 fast path)
   typedef double d2 __attribute__((ext_vector_type(2)));
   const int a = blockIdx.x, tid = threadIdx.x;
   const int done0 = st->done, head = st->hist_head, len = st->hist_len, n_it = st->n_iter;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
   d2 gv[NS], gov[NS], dv[NS], sav[NS], yav[NS];
 #pragma unroll
   for (int u = 0; u < NS; ++u) {
-    const int i = 2 * tid + u * 2 * LBD_THREADS;
+    const int i = 2 * tid + (u0 + u) * 2 * LBD_THREADS;
     const d2 z = {0.0, 0.0};
     gv[u] = gov[u] = dv[u] = sav[u] = yav[u] = z;
     if (i + 1 < n) {
@@ -435,11 +440,12 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
     };
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      const int i = 2 * tid + u * 2 * LBD_THREADS;
+      const int i = 2 * tid + (u0 + u) * 2 * LBD_THREADS;
       one(i, gv[u].x, gov[u].x, dv[u].x);
       one(i + 1, gv[u].y, gov[u].y, dv[u].y);
     }
-    for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS) one(i, g[i], g_old[i], d[i]);   // n > 4096: plain loop
+    if (HALVES == 1)
+      for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS) one(i, g[i], g_old[i], d[i]);   // n > 4096: plain loop
     block_sums(v, sh);
     if (tid == 0) {
       dots[5 * M1 + 0] = v[0]; dots[5 * M1 + 1] = v[1]; dots[5 * M1 + 2] = v[4]; dots[5 * M1 + 3] = v[5];
@@ -457,8 +463,9 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
       one(gv[u].x, gov[u].x, dv[u].x, sav[u].x, yav[u].x);
       one(gv[u].y, gov[u].y, dv[u].y, sav[u].y, yav[u].y);
     }
-    for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS)
-      one(g[i], g_old[i], d[i], Sh[(size_t)a * ring_ld(n) + i], Yh[(size_t)a * ring_ld(n) + i]);
+    if (HALVES == 1)
+      for (int i = tid + NS * 2 * LBD_THREADS; i < n; i += LBD_THREADS)
+        one(g[i], g_old[i], d[i], Sh[(size_t)a * ring_ld(n) + i], Yh[(size_t)a * ring_ld(n) + i]);
     block_sums(v, sh);
     if (tid == 0) {
       dots[a] = v[0]; dots[M1 + a] = v[1]; dots[2 * M1 + a] = v[2];
@@ -646,6 +653,11 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   } else {
     ys = pd[5 * M1 + 0]; yy = pd[5 * M1 + 1]; gg = pd[5 * M1 + 2]; gabs = pd[5 * M1 + 3]; sabs = pd[5 * M1 + 4];
     qv[0] = (wave < 5 && in_row) ? pd[wave * M1 + lane] : 0.0;
+    if (n_part == 2) {                               // k_lbc_dots<2>: the two halves of every dot product
+      const double* __restrict__ p2 = pd + ndp;
+      ys += p2[5 * M1 + 0]; yy += p2[5 * M1 + 1]; gg += p2[5 * M1 + 2]; gabs += p2[5 * M1 + 3]; sabs += p2[5 * M1 + 4];
+      qv[0] += (wave < 5 && in_row) ? p2[wave * M1 + lane] : 0.0;
+    }
   }
   const double ro_l0 = in_row ? ro_in[lane] : 0.0;
   const double f_new = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
