@@ -22,8 +22,8 @@ number read from a fixture the reference produced:
   4. for both L-BFGS kernels (mode 0 = the reference's operation order, mode 1 = compact form): the first iteration
      whose float64 loss departs from the reference's full-precision trace (burgers_default_trace.npz) by > 1e-6.
 north_star's literal "final L2 error within 1e-3 of reference" is recorded per dtype (`err_absdiff_vs_k0`); at the end of
-the full schedule it is a coin toss, not a property (f64 2.7e-3, then 9.9e-4 after the L-BFGS dot products were
-re-associated at the 1e-16 level; f32 2.3e-2): two runs of the reference itself differ by more (8 vs 4 torch threads:
+the full schedule it is a coin toss, not a property (f64 2.7e-3, then 9.9e-4, then 2.8e-3 as the L-BFGS dot products were
+re-associated twice at the 1e-16 level; f32 2.3e-2): two runs of the reference itself differ by more (8 vs 4 torch threads:
 0.26564 vs 0.26739) -- README.md states it.
 """
 import json
