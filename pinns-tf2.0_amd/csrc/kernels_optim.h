@@ -311,7 +311,7 @@ __global__ __launch_bounds__(LB_THREADS) void k_lbfgs_post(
 // ---------------------------------------------------------------------------------------------
 // Compact L-BFGS: same iteration as k_lbfgs_step, restructured so that no kernel contains a
 // chain of dependent full-length reductions.
-//   k_lbc_dots   one workgroup per history slot: every dot product this iteration needs
+//   k_lbc_dots   one workgroup per history slot (two, each on half of the vector, when n <= 4096): every dot product this iteration needs
 //                (s_a.y_c, s_c.y_a, y_a.y_c, s_a.g, y_a.g, y_c.s_c, y_c.y_c, g.g, |g|_1, |t d|_1) in
 //                parallel; also materialises the candidate pair s_c = t d, y_c = g - g_old.
 //   k_lbc_coef_apply   (a) the bookkeeping/break tests of custom_lbfgs.py:185-224 for the evaluation
@@ -598,7 +598,8 @@ constexpr int LBC_MAXSLOTS = 62;                  // one lane per ring slot
 //   sY[p][j] = y_p.y_j                              backward: y_p.q_0 -= al_j sY[p][j]
 //   sL[p][j] = ro_p (s_j.y_p) for j < p, else 0    forward:  e_p -= cs_j sL[p][j]; e_p is final (= cs_p)
 // (the zeros freeze a lane's value once its own step has passed).  Global reads stay in ring-slot
-// order and are issued as one round, including the vector operands of the update; the rotation by
+// order and are issued as one round (wave 0 includes its operands of the update; waves 1-15 fetch theirs while wave 0 runs
+// the recursion); the rotation by
 // `head` happens in the LDS write addresses.
 // d = cg g + sum_j (cy_j y_j + cs_j s_j) is summed over ring *slots* (zero coefficients for slots not
 // in use, ring zeroed at begin), 64 elements x 16 slices per workgroup, fixed order.
@@ -626,7 +627,8 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   double* const sZ = sP + 16 * 64;                 // 64 zeros: the matrix row of the lanes beyond M1
   double* const sQ = sZ + 64;                      // [3][LBP_PQ] dot products summed over a third of the tiles each
   CSTAMP(0);
-  // ---- every global read of this kernel, issued as ONE round (a dependent round costs 1.5-2 us)
+  // ---- every global read the recursion waits for, issued as ONE round (a dependent round costs 1.5-2 us; the round itself
+  // costs ~20 ticks per vector-memory instruction of the workgroup, so nothing is loaded twice and nothing early)
   const bool in_row = lane < M1;
   const LbfgsState s0 = *st_in;
   int head = uni(s0.hist_head), len = uni(s0.hist_len);
