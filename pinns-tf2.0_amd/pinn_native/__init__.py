@@ -41,16 +41,34 @@ def _build_tag():
     return " ".join(COMMON_FLAGS) + " | " + " ; ".join("%s %s" % (u, " ".join(f)) for u, f in UNITS)
 
 
+def _source_digest():
+    """sha256 over the kernel sources and the C header, in SOURCES order: what a library was built from"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(_CSRC, s) for s in SOURCES] + [HEADER]:
+        if os.path.exists(path):
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale(lib=None):
+    """A library is current when the flags file beside it names these flags AND these source contents (a digest, not
+    file times: a snapshot copied to another machine keeps no usable time order).  Without a flags file: file times."""
     lib = lib or LIB_PATH
     if not os.path.exists(lib):
         return True
+    tag = lib + ".flags"
+    if os.path.exists(tag):
+        lines = open(tag).read().split("\n")
+        digest = [l.split(" ", 1)[1] for l in lines if l.startswith("sources-sha256 ")]
+        if lines[0] != _build_tag():
+            return True
+        if digest:
+            return digest[0] != _source_digest()
     built = os.path.getmtime(lib)
     srcs = [os.path.join(_CSRC, s) for s in SOURCES] + [HEADER]
-    if any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs):
-        return True
-    tag = lib + ".flags"
-    return os.path.exists(tag) and open(tag).read().split("\n")[0] != _build_tag()
+    return any(os.path.exists(s) and os.path.getmtime(s) > built for s in srcs)
 
 
 def build(force=False, verbose=False, stamps=False):
@@ -75,6 +93,7 @@ def build(force=False, verbose=False, stamps=False):
         # VGPRs (csrc/fused20d_api.h), every other kernel keeps hipcc's default allocation; fused20m_unit.hip holds
         # the float32 register-stash kernel at the depths other than 8
         common = [hipcc] + COMMON_FLAGS + (["-DPINN_STAMPS"] if stamps else [])
+        digest = _source_digest()
         with tempfile.TemporaryDirectory(prefix="pinn_build_", dir=_HERE) as tmp:
             objs, procs = [], []
             for src, extra in UNITS:
@@ -103,7 +122,8 @@ def build(force=False, verbose=False, stamps=False):
                 os.replace(obj, os.path.join(_HERE, os.path.basename(obj).replace(".o", "_stamps.o" if stamps else ".o")))
         ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
         with open(out + ".flags", "w") as fh:                  # flags + the compiler the kernels were validated with
-            fh.write(_build_tag() + ("\n-DPINN_STAMPS" if stamps else "") + "\n" + "\n".join(ver[:3]) + "\n")
+            fh.write(_build_tag() + ("\n-DPINN_STAMPS" if stamps else "") + "\nsources-sha256 " + digest + "\n" +
+                     "\n".join(ver[:3]) + "\n")
     return out
 
 
