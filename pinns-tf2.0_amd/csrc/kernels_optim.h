@@ -16,7 +16,8 @@ constexpr int RED_COLS = 64;
 constexpr int RED_SLICES = 16;
 constexpr int RED_THREADS = RED_COLS * RED_SLICES;   // (measured: 8 / 16 / 32 columns per workgroup, i.e. 8x / 4x / 2x the
                                                      //  workgroups, are no faster: f64 Adam step 41.9 / 40.9 / 40.6 vs 40.9 us; neither are two columns per thread
-                                                     //  on an even row pitch, 512 threads, bit-identical sums: 41.3 vs 40.8 us, f32 29.3 vs 28.3)
+                                                     //  on an even row pitch, 512 threads, bit-identical sums: 41.3 vs 40.8 us, f32 29.3 vs 28.3; nor non-temporal row
+                                                     //  loads: 41.9 vs 40.8 us -- part of the rows is still in an L2)
 
 template <typename real>
 __device__ __forceinline__ double reduce_column(const real* __restrict__ part, int n_rows, int R,
