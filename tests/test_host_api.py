@@ -145,6 +145,29 @@ def test_c_abi_exports_every_declared_symbol():
     assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
 
 
+def test_library_staleness_is_decided_by_source_contents_not_file_times(monkeypatch):
+    """pinn_native._stale(): a library whose flags file records these flags and the digest of these sources is current
+    whatever the file times say (a snapshot copied to a GPU box keeps no usable time order); any change of a source, or
+    of the compile flags, makes it stale; a library named by PINN_HIP_LIB is never rebuilt"""
+    import pinn_native
+    pinn_native.load()                                          # builds if needed, writes libpinn_hip.so.flags
+    tag = pinn_native.LIB_PATH + ".flags"
+    assert os.path.exists(tag) and "sources-sha256 " in open(tag).read()
+    assert not pinn_native._stale()
+    src = os.path.join(os.path.dirname(os.path.dirname(pinn_native.LIB_PATH)), "csrc", "wave.h")
+    st = os.stat(src)
+    try:
+        os.utime(src)                                           # newer than the library, same content
+        assert not pinn_native._stale()
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    monkeypatch.setattr(pinn_native, "_source_digest", lambda: "0" * 64)
+    assert pinn_native._stale()
+    monkeypatch.undo()
+    monkeypatch.setattr(pinn_native, "COMMON_FLAGS", pinn_native.COMMON_FLAGS + ["-DSOMETHING"])
+    assert pinn_native._stale()
+
+
 def test_c_abi_rejects_bad_arguments_without_a_gpu():
     import pinn_native
     lib = pinn_native.load()
