@@ -387,7 +387,7 @@ def main():
         if world == 1:
             return "none"
         from pinn_native.parallel import init_engine_comm
-        return init_engine_comm(eng, dist, world, rank)          # "rccl" unless PINN_COMM=auto and the mailboxes win
+        return init_engine_comm(eng, dist, world, rank, probe=True)   # "rccl" unless PINN_COMM=auto and the mailboxes win
 
     # ---- headline leg ---------------------------------------------------------------------------------------
     main_leg, eng = leg("headline", args.dtype, device, data, w0, wd, k_adam, k_lbfgs, args.warmup, args.kernel_path,

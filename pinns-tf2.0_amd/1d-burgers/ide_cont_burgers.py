@@ -58,6 +58,8 @@ class BurgersInformedNN(NeuralNetwork):
         """Residual f = u_t + l1 u u_x - exp(l2) u_xx at the points X_u [N, 2] (:56-85); without an argument, at
         the bound data points.  [N, 1]."""
         if X_u is None:
+            if self._dp:                         # a rank holds its block of the data set: evaluate the full set
+                return self._engine.residual_at(self._X_bound)
             return self._engine.residual()
         return self._engine.residual_at(np.asarray(X_u, dtype=np.float64))
 
@@ -105,12 +107,13 @@ if __name__ == "__main__":
     pinn.fit(X_u_train, u_train)
     lambda_1_pred_noise, lambda_2_pred_noise = pinn.get_params(numpy=True)
 
-    print("l1: ", lambda_1_pred)
-    print("l2: ", lambda_2_pred)
-    print("l1_noise: ", lambda_1_pred_noise)
-    print("l2_noise: ", lambda_2_pred_noise)
+    if pinn.is_root:
+        print("l1: ", lambda_1_pred)
+        print("l2: ", lambda_2_pred)
+        print("l1_noise: ", lambda_1_pred_noise)
+        print("l2_noise: ", lambda_2_pred_noise)
 
-    if not os.environ.get("PINN_NO_PLOT"):
+    if not os.environ.get("PINN_NO_PLOT") and pinn.is_root:
         plot_ide_cont_results(X_star, u_pred, X_u_train, u_train, Exact_u, X, T, x, t,
                               lambda_1_pred, lambda_1_pred_noise, lambda_2_pred,
                               lambda_2_pred_noise, save_path=os.path.join(_root, eqnPath),

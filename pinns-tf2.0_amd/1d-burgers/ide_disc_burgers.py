@@ -151,12 +151,13 @@ if __name__ == "__main__":
     U_0_pred, U_1_pred = pinn.predict(x_star)
     lambda_1_pred_noisy, lambda_2_pred_noisy = pinn.get_params(numpy=True)
 
-    print("l1: ", lambda_1_pred)
-    print("l2: ", lambda_2_pred)
-    print("noisy l1: ", lambda_1_pred_noisy)
-    print("noisy l2: ", lambda_2_pred_noisy)
+    if pinn.is_root:                 # under torchrun the discrete-time models are replicas; rank 0 reports
+        print("l1: ", lambda_1_pred)
+        print("l2: ", lambda_2_pred)
+        print("noisy l1: ", lambda_1_pred_noisy)
+        print("noisy l2: ", lambda_2_pred_noisy)
 
-    if not os.environ.get("PINN_NO_PLOT"):
+    if not os.environ.get("PINN_NO_PLOT") and pinn.is_root:
         plot_ide_disc_results(x_star, t_star, idx_t_0, idx_t_1, x_0, u_0, x_1, u_1, ub, lb, U_1_pred, Exact_u,
                               lambda_1_pred, lambda_1_pred_noisy, lambda_2_pred, lambda_2_pred_noisy,
                               x_star, t_star, save_path=os.path.join(_root, eqnPath), save_hp=hp)

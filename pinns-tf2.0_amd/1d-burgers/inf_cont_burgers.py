@@ -45,7 +45,7 @@ class BurgersInformedNN(NeuralNetwork):
         X_f = np.asarray(X_f, dtype=np.float64)
         self.x_f = self.tensor(X_f[:, 0:1])
         self.t_f = self.tensor(X_f[:, 1:2])
-        self._engine.set_collocation(X_f)
+        self._set_collocation(X_f)               # this rank's block when launched data-parallel
         self._engine.set_pde_params(nu)
 
     def loss(self, u, u_pred):
@@ -56,7 +56,7 @@ class BurgersInformedNN(NeuralNetwork):
 
     def f_model(self):
         """Residual at the collocation points, [N_f, 1]."""
-        return self._engine.residual()
+        return self._residual_collocation()
 
     def get_params(self, numpy=False):
         return self.nu
@@ -83,11 +83,11 @@ def run(hp):
     pinn.fit(X_u_train, u_train)
 
     u_pred = pinn.predict(X_star)[0]
-    if not os.environ.get("PINN_NO_PLOT"):
+    if not os.environ.get("PINN_NO_PLOT") and pinn.is_root:
         plot_inf_cont_results(X_star, u_pred.flatten(), X_u_train, u_train, Exact_u, X, T, x, t,
                               save_path=os.path.join(_root, eqnPath), save_hp=hp, weights=pinn.get_weights())
     return pinn
 
 
 if __name__ == "__main__":
-    run(hp)
+    pinn = run(hp)

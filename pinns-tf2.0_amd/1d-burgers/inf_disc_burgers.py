@@ -113,6 +113,6 @@ if __name__ == "__main__":
     pinn.fit(x_0, u_0)
 
     u_1_pred = pinn.predict(x_star)
-    if not os.environ.get("PINN_NO_PLOT"):
+    if not os.environ.get("PINN_NO_PLOT") and pinn.is_root:
         plot_inf_disc_results(x_star, idx_t_0, idx_t_1, x_0, u_0, ub, lb, u_1_pred, Exact_u, x, t,
                               save_path=os.path.join(_root, eqnPath), save_hp=hp)

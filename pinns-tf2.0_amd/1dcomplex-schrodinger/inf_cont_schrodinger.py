@@ -48,26 +48,27 @@ class SchrodingerInformedNN(NeuralNetwork):
         X_f = np.asarray(X_f, dtype=np.float64)
         self.x_f = self.tensor(X_f[:, 0:1])
         self.t_f = self.tensor(X_f[:, 1:2])
-        self._engine.set_collocation(X_f)
-        self._engine.set_boundary(X_lb, X_ub)
+        self._set_collocation(X_f)               # these two are split over the ranks of a data-parallel launch
+        self._set_boundary(X_lb, X_ub)
 
     def f_model(self):
         """(f_u, f_v) at the collocation points, each [N_f, 1]."""
-        f = self._engine.residual()
+        f = self._residual_collocation()
         return f[:, 0:1], f[:, 1:2]
 
     def loss(self, uv, uv_pred):
         """Total loss at the current weights for the bound IC set; the three parts are printed
         like the reference does on every evaluation (:128)."""
         total, _, terms = self._engine.loss_grad(want_grad=False)
-        print(f"mse_0 {terms[1]}    mse_b {terms[2]}    mse_f    {terms[0]}")
+        if self.is_root:
+            print(f"mse_0 {terms[1]}    mse_b {terms[2]}    mse_f    {terms[0]}")
         return total
 
     def _adam_chunk(self, n):
         """The reference prints the three parts inside loss(), i.e. once per epoch (:128): same lines, same order
         relative to the progress lines, emitted when the chunk's losses come back from the device."""
         terms = self._engine.adam_run_terms(n)
-        if not self._quiet_parts:
+        if not self._quiet_parts and self.is_root:
             for res, data, bnd in terms:
                 print(f"mse_0 {data}    mse_b {bnd}    mse_f    {res}")
         return terms.sum(axis=1)
@@ -95,6 +96,6 @@ if __name__ == "__main__":
 
     u_pred, v_pred = pinn.predict(X_star)
     h_pred = np.sqrt(u_pred ** 2 + v_pred ** 2)
-    if not os.environ.get("PINN_NO_PLOT"):
+    if not os.environ.get("PINN_NO_PLOT") and pinn.is_root:
         plot_inf_cont_results(X_star, u_pred, v_pred, h_pred, Exact_h, X, T, x, t, ub, lb, x0, tb,
                               save_path=os.path.join(_root, eqnPath), save_hp=hp)

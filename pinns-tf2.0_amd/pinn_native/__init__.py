@@ -214,6 +214,13 @@ def load():
         raise PinnNativeError(
             "libpinn_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; "
             "g.build()'`.  There is no CPU fallback." % LIB_PATH)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # one rank of a torchrun launch: torch.distributed (rendezvous) will be imported sooner or later, and it brings
+        # its own copies of the HIP runtime and RCCL.  Import it BEFORE the engine so that both resolve to one set.
+        try:
+            import torch.distributed  # noqa: F401
+        except ImportError:
+            pass
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

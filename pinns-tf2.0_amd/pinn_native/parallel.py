@@ -21,6 +21,54 @@ def env_world():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+class DataParallel(object):
+    """What the drop-in classes (utils/neuralnetwork.py) need from the process group: who am I, which block of a point
+    set is mine, and a digest comparison across the replicas.  torch.distributed (gloo) is rendezvous only; the
+    gradient exchange itself happens inside the engine (RCCL / mailboxes, see init_engine_comm)."""
+
+    def __init__(self, dist, world, rank, local_rank):
+        self.dist, self.world, self.rank, self.local_rank = dist, int(world), int(rank), int(local_rank)
+
+    @property
+    def is_root(self):
+        return self.rank == 0
+
+    def shard(self, n):
+        return shard_bounds(n, self.world, self.rank)
+
+    def replicas_identical(self, w):
+        """every rank holds bit-identical weights (they are never broadcast: they stay equal because every rank applies
+        the same update to the same all-reduced gradient).  Collective."""
+        import hashlib
+        digests = [None] * self.world
+        self.dist.all_gather_object(digests, hashlib.sha256(w.tobytes()).hexdigest())
+        return all(d == digests[0] for d in digests)
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def is_root():
+    """rank 0 of a torchrun launch, or a plain single-process run: the one process that prints, plots and saves"""
+    world, rank, _ = env_world()
+    return world == 1 or rank == 0
+
+
+def from_env(enabled=True):
+    """-> DataParallel when this process is one rank of `python -m torch.distributed.run --nproc-per-node N script.py`
+    (WORLD_SIZE > 1), else None.  Joins the gloo process group on first use (MASTER_ADDR / MASTER_PORT from the
+    launcher; 127.0.0.1 when unset)."""
+    world, rank, local = env_world()
+    if world <= 1 or not enabled:
+        return None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return DataParallel(dist, world, rank, local)
+
+
 def attach_shards(engine, world, rank, X_f=None, X_u=None, u=None, X_lb=None, X_ub=None):
     """Give `engine` this rank's block of every point set; mean() denominators stay global so
     that the per-rank partial sums add up to the single-process loss and gradient."""
@@ -35,7 +83,7 @@ def attach_shards(engine, world, rank, X_f=None, X_u=None, u=None, X_lb=None, X_
         engine.set_boundary(X_lb[lo:hi], X_ub[lo:hi], n_total=len(X_lb))
 
 
-def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
+def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True, probe=False):
     """Create the communicator of `engine`.
 
     RCCL: rank 0 draws the unique id, torch.distributed (any backend; gloo in this repo) broadcasts it, every
@@ -44,7 +92,9 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
     peer-mapped mailbox all-reduce of csrc/kernels_xgmi.h is set up on top: handles are all-gathered, every rank
     attaches and self-tests, both implementations are timed on the node, and the mailboxes are switched on only
     if *every* rank reports success and they are not slower -- otherwise all ranks stay on RCCL.
-    Returns the mode in use ("rccl" or "mailbox")."""
+    probe=True (bench.py) additionally times one exchange on the node under the RCCL default -> engine.comm_probe_us;
+    the ranks first agree that every one of them holds a communicator, so that no rank enters the timed collective
+    alone.  Returns the mode in use ("rccl" or "mailbox")."""
     from . import Engine, PinnNativeError
     policy = os.environ.get("PINN_COMM", "rccl").lower()     # rccl (default) | auto | mailbox-only (no RCCL communicator)
     if policy == "mailbox-only":
@@ -57,16 +107,21 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True):
         mailbox = policy != "rccl"
     engine.comm_probe_us = None
     if not mailbox:
-        # what one exchange of the [P+4] vector costs on this node (k_reduce_rows + ncclAllReduce, wall time per
-        # iteration, MAX over ranks): the number the 8-GPU budget of DESIGN.md 6 needs.  Collective, every rank calls it.
-        try:
-            mine = engine.comm_benchmark("rccl")
-        except PinnNativeError:
-            mine = None
-        probes = [None] * world
-        dist.all_gather_object(probes, mine)
-        if all(p is not None for p in probes):
-            engine.comm_probe_us = {"rccl": max(probes)}
+        if probe:
+            # what one exchange of the [P+4] vector costs on this node (k_reduce_rows + ncclAllReduce, wall time per
+            # iteration, MAX over ranks): the number the 8-GPU budget of DESIGN.md 6 needs.  The probe is a collective:
+            # it runs only after every rank has said it is about to enter it.
+            ready = [None] * world
+            dist.all_gather_object(ready, engine.comm_mode() == "rccl" if hasattr(engine, "comm_mode") else True)
+            if all(ready):
+                try:
+                    mine = engine.comm_benchmark("rccl")
+                except PinnNativeError:
+                    mine = None
+                probes = [None] * world
+                dist.all_gather_object(probes, mine)
+                if all(p is not None for p in probes):
+                    engine.comm_probe_us = {"rccl": max(probes)}
         return "rccl"
     try:
         mine = engine.comm_xgmi_export(world, rank)

@@ -7,12 +7,19 @@ log_train_opt, log_train_end -- and byte-compatible progress lines, e.g.
     Training finished (epoch 300): duration = 00:19  error = 2.6564e-01  
 
 Only the three TensorFlow banner lines differ: they report the HIP engine and device.
+In a data-parallel launch (torchrun, WORLD_SIZE > 1) rank 0 alone prints; the other ranks' Logger is silent
+(and never calls the error function).
 The loss handed to log_train_epoch is a host float that the engine copies back only at
 log points, so logging does not force a device sync per iteration as the reference does.
 """
 import json
+import os
 import time
 from datetime import datetime
+
+
+def _is_root():
+    return int(os.environ.get("WORLD_SIZE", "1")) <= 1 or int(os.environ.get("RANK", "0")) == 0
 
 
 def _engine_banner():
@@ -52,10 +59,12 @@ _END_LINE = "Training finished (epoch {epoch}): duration = {total}  error = {err
 
 class Logger(object):
     def __init__(self, hp):
-        banner = ["Hyperparameters:", json.dumps(hp, indent=2), ""]
-        engine, device, on_gpu = _engine_banner()
-        banner += ["Engine: %s" % engine, "Device: %s" % device, "GPU-accerelated: %s" % on_gpu]
-        print("\n".join(banner))
+        self.quiet = not _is_root()
+        if not self.quiet:
+            banner = ["Hyperparameters:", json.dumps(hp, indent=2), ""]
+            engine, device, on_gpu = _engine_banner()
+            banner += ["Engine: %s" % engine, "Device: %s" % device, "GPU-accerelated: %s" % on_gpu]
+            print("\n".join(banner))
         self._clock = _Clock()
         self.frequency = hp["log_frequency"]
         self.error_fn = None
@@ -79,21 +88,27 @@ class Logger(object):
 
     def log_train_start(self, model, model_description=False):
         self.model = model
+        if self.quiet:
+            return
         print("\nTraining started\n================")
         if model_description:
             print(model.summary())
 
     def log_train_opt(self, name):
+        if self.quiet:
+            return
         print("-- Starting %s optimization --" % name)
 
     def log_train_epoch(self, epoch, loss, custom="", is_iter=False):
-        if epoch % self.frequency:
+        if self.quiet or epoch % self.frequency:
             return
         print(_EPOCH_LINE.format(tag="nt_epoch" if is_iter else "tf_epoch", epoch=int(epoch),
                                  total=self._clock.total(), lap=self._clock.lap(), loss=float(loss),
                                  custom=custom))
 
     def log_train_end(self, epoch, custom=""):
+        if self.quiet:
+            return
         print("==================")
         print(_END_LINE.format(epoch=epoch, total=self._clock.total(), err=float(self.get_error_u()),
                                custom=custom))

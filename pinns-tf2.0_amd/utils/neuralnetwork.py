@@ -13,7 +13,16 @@ It names one of the engine's residual kinds instead (`pde="burgers" | "burgers_i
 "schrodinger" | "burgers_disc" | "burgers_disc_ide"`) and the engine evaluates forward, u_t/u_x/u_xx, residual, loss and the flat
 gradient on the GPU (csrc/).  Extra, optional hp keys: "dtype" ("f64" default = the reference's
 arithmetic, neuralnetwork.py:24-26 | "f32" = the throughput mode north_star sanctions) for the
-kernel arithmetic, "device" (HIP ordinal).  Host interchange stays float64.
+kernel arithmetic, "device" (HIP ordinal), "nt_guard" (see nt_optimization).  Host interchange stays float64.
+
+Data parallel (north_star; the reference has no distributed code): launched as
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 1d-burgers/inf_cont_burgers.py [hp.json]
+every process is one rank of ONE model: device = LOCAL_RANK, the collocation / data / boundary sets handed to the
+class are split in contiguous blocks over the ranks (mean() denominators stay global), the engines exchange the
+[P+4] float64 gradient vector once per evaluation (RCCL all-reduce over xGMI), every rank applies the same optimiser
+update to its replica, and rank 0 alone prints, plots and saves.  hp["data_parallel"] = false keeps N independent
+full-batch replicas.  Everything a script calls keeps its single-process meaning: predict / f_model / error_l2 return
+full arrays on every rank.
 
 There is no CPU path: constructing a NeuralNetwork without the HIP library or a GPU raises.
 """
@@ -26,7 +35,7 @@ from custom_lbfgs import lbfgs, Struct
 import os
 import sys
 sys.path.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from pinn_native import Engine  # noqa: E402
+from pinn_native import Engine, parallel  # noqa: E402
 
 
 _INIT_STREAM = {"seed": 1234, "rs": None}
@@ -99,6 +108,7 @@ def _as_points(X, owner):
 
 class NeuralNetwork(object):
     pde = "burgers"
+    MAX_RESTARTS = 5            # nt_guard: discards per nt_optimization call
 
     def __init__(self, hp, logger, ub, lb, pde=None):
         layers = hp["layers"]
@@ -121,8 +131,19 @@ class NeuralNetwork(object):
         self.ub = np.asarray(ub, dtype=np.float64)
         self.lb = np.asarray(lb, dtype=np.float64)
 
+        # one rank of a torchrun launch = one shard of the point sets on GPU LOCAL_RANK (module docstring); the
+        # discrete-time models hold <= 256 points and stay replicated
+        self._dp = None if self.pde.startswith("burgers_disc") else parallel.from_env(bool(hp.get("data_parallel", True)))
+        self.is_root = parallel.is_root()
+        world, _, local_rank = parallel.env_world()
+        device = hp.get("device", os.environ.get("PINN_DEVICE", local_rank if world > 1 else 0))
         self._engine = Engine(self.layers, self.lb, self.ub, pde=self.pde,
-                              dtype=self.compute_dtype, device=int(hp.get("device", 0)))
+                              dtype=self.compute_dtype, device=int(device))
+        self.comm_mode = "none"
+        if self._dp:
+            self.comm_mode = parallel.init_engine_comm(self._engine, self._dp.dist, self._dp.world, self._dp.rank)
+        self._X_f = None
+        self._n_f_total = 0
         self.model = _ModelView(self, self.layers)
 
         # flat-layout bookkeeping, same rule as the reference (all hidden widths = layers[1])
@@ -144,6 +165,37 @@ class NeuralNetwork(object):
         # samples once on the host).  Seeds are resample_seed + epoch.
         self._resample_every = int(hp.get("resample_every", 0))
         self._resample_seed = int(hp.get("resample_seed", 1234))
+        # L-BFGS restart guard (nt_optimization): off in the reference's arithmetic, on in float32
+        guard = hp.get("nt_guard", 1e3 if self.compute_dtype in ("f32", "float32") else 0.0)
+        self._nt_guard = float(guard or 0.0)
+        self.nt_restarts = []
+
+    # ---- point sets (sharded over the ranks of a data-parallel launch) ---------------------------
+    def _set_collocation(self, X_f):
+        """collocation points of the residual term (1d-burgers/inf_cont_burgers.py:55-56): this rank's block goes to
+        the GPU, the mean keeps its global denominator"""
+        X_f = np.ascontiguousarray(np.asarray(X_f, dtype=np.float64).reshape(-1, 2))
+        self._X_f, self._n_f_total = X_f, X_f.shape[0]
+        if self._dp:
+            lo, hi = self._dp.shard(X_f.shape[0])
+            self._engine.set_collocation(X_f[lo:hi], n_total=X_f.shape[0])
+        else:
+            self._engine.set_collocation(X_f)
+
+    def _set_boundary(self, X_lb, X_ub):
+        """periodic-boundary pairs (1dcomplex-schrodinger/inf_cont_schrodinger.py:50-53); a pair stays on one rank"""
+        if self._dp:
+            lo, hi = self._dp.shard(len(X_lb))
+            self._engine.set_boundary(X_lb[lo:hi], X_ub[lo:hi], n_total=len(X_lb))
+        else:
+            self._engine.set_boundary(X_lb, X_ub)
+
+    def _residual_collocation(self):
+        """f at ALL collocation points [N_f, n_out], on every rank (a shard holds only its block: the replicated
+        weights are evaluated at the full set instead)"""
+        if self._dp and self._X_f is not None:
+            return self._engine.residual_at(self._X_f)
+        return self._engine.residual()
 
     # ---- initialisation ------------------------------------------------------------------------
     def _n_net(self):
@@ -192,8 +244,13 @@ class NeuralNetwork(object):
         if key is None:
             key = self._digest(X, u)
         if key != self._bound:
-            self._engine.set_data(X, u)
+            if self._dp:                     # this rank's block of the data set; mean() over the global count
+                lo, hi = self._dp.shard(X.shape[0])
+                self._engine.set_data(X[lo:hi], u[lo:hi], n_total=X.shape[0])
+            else:
+                self._engine.set_data(X, u)
             self._bound = key
+            self._X_bound = X
         return key
 
     def _split(self, flat):
@@ -261,10 +318,14 @@ class NeuralNetwork(object):
         self._bind(X_u, u)
         freq = max(int(self.logger.frequency), 1)
         epoch = 0
-        every = self._resample_every if self._engine.n_f > 0 else 0
+        n_design = self._n_f_total or self._engine.n_f
+        every = self._resample_every if n_design > 0 else 0
         while epoch < self.tf_epochs:
             if every and epoch > 0 and epoch % every == 0:
-                self._engine.lhs_collocation(self._engine.n_f, self._resample_seed + epoch)
+                # one design for the whole job; a rank draws its own block of it (counter-based: no communication)
+                lo, hi = self._dp.shard(n_design) if self._dp else (0, n_design)
+                self._engine.lhs_collocation(n_design, self._resample_seed + epoch, first=lo, count=hi - lo)
+                self._X_f = None
             # run up to and including the next epoch that is logged, then sync once
             stop = min(self.tf_epochs, (epoch + freq - 1) // freq * freq + 1)
             if every:
@@ -294,15 +355,49 @@ class NeuralNetwork(object):
         cfg = self.nt_config
         if cfg.maxIter == 0:
             return
-        self._engine.lbfgs_begin(cfg.maxIter, cfg.learningRate or 1, cfg.nCorrection or 100,
-                                 cfg.tolFun or 1e-5, cfg.tolX or 1e-19, cfg.maxEval or 0.0)
+
+        def begin(iters_left):
+            self._engine.lbfgs_begin(iters_left, cfg.learningRate or 1, cfg.nCorrection or 100,
+                                     cfg.tolFun or 1e-5, cfg.tolX or 1e-19, cfg.maxEval or 0.0)
+
+        begin(cfg.maxIter)
         freq = max(int(self.logger.frequency), 1)
-        done = 0
+        # Restart guard, hp["nt_guard"] = G (default 1e3 in float32, 0 = off in float64 = the reference's behaviour).
+        # The reference's L-BFGS has no line search (utils/custom_lbfgs.py:159-163: t = learningRate): a curvature
+        # pair with y.s barely above its 1e-10 test makes the next step arbitrarily long, and the run is lost -- in
+        # ANY arithmetic (profiles/r04_diag_f32_k-10_shadow.txt: the float64 update from float64 pairs takes the
+        # same step).  With G > 0 a chunk of iterations whose loss becomes non-finite or exceeds G x the lowest loss
+        # accepted so far is discarded: the weights go back to the last accepted chunk boundary and L-BFGS starts
+        # again there with an empty history for the iterations that are left.  A run that never explodes is
+        # untouched (same kernels, same iterates); at most MAX_RESTARTS discards per call.
+        guard, base, restarts, done = self._nt_guard, 0, 0, 0
+        best = np.inf                                       # lowest loss of an accepted chunk
+        keep_w, keep_it = (self._engine.get_weights(), 0) if guard > 0 else (None, 0)
         while not done:
             iters, losses, done = self._engine.lbfgs_run(freq)
+            if guard > 0 and len(losses):
+                if not np.isfinite(best):
+                    if not np.isfinite(losses[0]):          # already lost before L-BFGS started: nothing to go back to
+                        guard = 0.0
+                    best = float(losses[0])
+                bad = (~np.isfinite(losses)) | (losses > guard * best) if guard > 0 else np.zeros(len(losses), bool)
+                if bad.any() and restarts < self.MAX_RESTARTS and keep_it < cfg.maxIter:
+                    k = int(np.argmax(bad))
+                    restarts += 1
+                    self.nt_restarts.append((base + int(iters[k]), keep_it))
+                    if self.is_root:
+                        print("nt_guard: loss %.3e at L-BFGS iteration %d (lowest accepted %.3e): discarded, restarting "
+                              "from iteration %d" % (float(losses[k]), base + int(iters[k]), best, keep_it), file=sys.stderr)
+                    self._engine.set_weights(keep_w)
+                    base, done = keep_it, 0
+                    begin(cfg.maxIter - base)
+                    continue
             for k, (it, loss_value) in enumerate(zip(iters, losses)):
                 custom = self._log_custom() if k == len(iters) - 1 else ""
-                self.logger.log_train_epoch(int(it), loss_value, custom, True)
+                self.logger.log_train_epoch(base + int(it), loss_value, custom, True)
+            if guard > 0 and len(iters) and not done:
+                best = min(best, float(np.min(losses)))
+                keep_w, keep_it = self._engine.get_weights(), base + int(iters[-1])
 
     def nt_optimization_steps(self, loss_and_flat_grad):
         """Host-driven variant with the reference's signature: any closure w -> (loss, grad)."""
@@ -318,6 +413,9 @@ class NeuralNetwork(object):
         self.tf_optimization(X_u, u)
         self.nt_optimization(X_u, u)
         self.logger.log_train_end(self.tf_epochs + self.nt_config.maxIter)
+        if self._dp and not self._dp.replicas_identical(self._engine.get_weights()):
+            raise RuntimeError("data-parallel replicas hold different weights after training (rank %d of %d)"
+                               % (self._dp.rank, self._dp.world))
         bad = self._engine.status()[1]
         if bad:
             print("warning: the loss became non-finite at evaluation %d" % bad, file=sys.stderr)

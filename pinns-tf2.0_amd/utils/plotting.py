@@ -34,7 +34,14 @@ def savefig(filename, crop=True):
     plt.savefig("{}.png".format(filename), **kw)
 
 
+def is_root():
+    """rank 0 of a data-parallel launch (or a plain run): the one process that writes results/"""
+    return int(os.environ.get("WORLD_SIZE", "1")) <= 1 or int(os.environ.get("RANK", "0")) == 0
+
+
 def saveResultDir(save_path, save_hp, weights=None):
+    if not is_root():
+        return None
     stamp = datetime.now().strftime("%Y%m%d-%H%M%S")
     script = os.path.splitext(os.path.basename(sys.argv[0]))[0]
     res_dir = os.path.join(save_path, "results", "{}-{}".format(stamp, script))

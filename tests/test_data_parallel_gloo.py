@@ -292,3 +292,148 @@ def test_bench_main_world2_emits_one_contract_line(tmp_path):
     for r in range(2):
         sets = open(tmp_path / ("rank%d.sets" % r)).read().split(";")
         assert sets == ["f64:5000:(2, %d)" % r, "f32:5000:(2, %d)" % r, "f64:500000:(2, %d)" % r], sets
+
+
+# ---- the drop-in classes launched data-parallel (world_size 2 over gloo, scripted engine) ---------------------------------
+class _SurfaceEngine(object):
+    """what utils/neuralnetwork.py and the scripts' classes touch of pinn_native.Engine; records the point sets it is
+    given; 'training' moves the weights by a function of the (all-reduced, hence rank-independent) step count only --
+    unless the scenario makes one rank drift"""
+    made = []
+    drift_rank = None
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f64", device=0):
+        self.layers, self.pde, self.dtype, self.device = layers, pde, dtype, device
+        self.n_params = sum(a * b + b for a, b in zip(layers[:-1], layers[1:])) + (2 if pde == "burgers_ide" else 0)
+        self.w = np.zeros(self.n_params)
+        self.n_f = self.n_u = self.n_b = 0
+        self.sets, self.comm, self.steps = {}, None, 0
+        _SurfaceEngine.made.append(self)
+
+    def set_collocation(self, X, n_total=None): self.n_f = len(X); self.sets["f"] = (np.array(X), n_total)
+    def set_data(self, X, u, n_total=None): self.n_u = len(X); self.sets["u"] = (np.array(X), np.array(u), n_total)
+    def set_boundary(self, A, B, n_total=None): self.n_b = len(A); self.sets["b"] = (np.array(A), np.array(B), n_total)
+    def set_pde_params(self, *p): pass
+    def set_weights(self, w): self.w = np.array(w, dtype=np.float64)
+    def get_weights(self): return self.w.copy()
+    def adam_init(self, *a): pass
+
+    def _walk(self, n):
+        self.steps += n
+        self.w = self.w + 1e-3 * n + (1e-9 if _SurfaceEngine.drift_rank == int(os.environ["RANK"]) else 0.0)
+
+    def adam_run(self, n, want_losses=True): self._walk(n); return 1.0 / (self.steps - np.arange(n)[::-1] + 1.0)
+    def adam_run_terms(self, n): self._walk(n); return np.full((n, 3), 0.1)
+    def lbfgs_begin(self, n, *a): self.left, self.it = n, 0
+
+    def lbfgs_run(self, n):
+        k = min(n, self.left)
+        self.left -= k
+        its = np.arange(self.it + 1, self.it + k + 1 - (1 if self.left == 0 else 0), dtype=np.int32)
+        self.it += k
+        self._walk(k)
+        return its, 0.5 / (its + 1.0), int(self.left == 0)
+
+    def loss_grad(self, want_grad=True): return 0.3, (np.zeros(self.n_params) if want_grad else None), np.array([0.1, 0.1, 0.1])
+    def predict(self, X): return np.zeros((len(X), self.layers[-1]))
+    def residual(self): return np.zeros((self.n_f, self.layers[-1]))
+    def residual_at(self, X): return np.zeros((len(X), self.layers[-1]))
+    def error_l2(self, X, ref, modulus=False): return 0.25
+    def status(self): return self.steps, 0
+    def comm_init(self, uid, world, rank): self.comm = (world, rank)
+    def comm_mode(self): return "rccl" if self.comm else "none"
+    def comm_benchmark(self, mode, iters=200): raise AssertionError("the drop-in surface must not run the timing probe")
+    def close(self): pass
+
+    @staticmethod
+    def comm_unique_id(): return b"u" * 128
+
+
+def _surface_worker(rank, world, port, out_dir, which, drift):
+    for p in (ROOT, PKG, os.path.join(PKG, "utils"), os.path.join(PKG, "1d-burgers"), os.path.join(PKG, "1dcomplex-schrodinger")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank), PINN_NO_PLOT="1")
+    os.environ.pop("PINN_COMM", None)
+    os.environ.pop("PINN_DEVICE", None)
+    import contextlib
+    import importlib
+    import io
+    import pinn_native
+    pinn_native.Engine = _SurfaceEngine
+    pinn_native.device_info = lambda d=0: {"name": "stub", "compute_units": 256, "hbm_bytes": 0}
+    pinn_native.device_count = lambda: 2
+    _SurfaceEngine.drift_rank = drift
+    sys.argv = ["script"]
+    buf, err = io.StringIO(), ""
+    with contextlib.redirect_stdout(buf):
+        import neuralnetwork
+        neuralnetwork.Engine = _SurfaceEngine
+        try:
+            if which == "burgers":
+                mod = importlib.import_module("inf_cont_burgers")
+                pinn = mod.run(dict(mod.hp, N_u=63, N_f=1001, tf_epochs=12, nt_epochs=7, log_frequency=5))
+                X_f_full = None
+            else:
+                import runpy
+                g = runpy.run_path(os.path.join(PKG, "1dcomplex-schrodinger", "inf_cont_schrodinger.py"), run_name="schro")
+                hp = dict(g["hp"], N_0=51, N_b=37, N_f=2003, tf_epochs=6, log_frequency=3)
+                import schrodingerutil
+                from logger import Logger
+                np.random.seed(1234)
+                r = schrodingerutil.prep_data(os.path.join(PKG, "1dcomplex-schrodinger", "data", "NLS.mat"), 51, 37, 2003, noise=0.0)
+                X_f, ub, lb, tb, x0, u0, v0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17]
+                pinn = g["SchrodingerInformedNN"](hp, Logger(hp), X_f, tb, ub, lb)
+                pinn.logger.set_error_fn(lambda: 0.5)
+                pinn.fit(x0, np.concatenate([u0, v0], 1))
+                assert pinn.f_model()[0].shape == (2003, 1)          # full arrays on every rank
+        except RuntimeError as e:
+            err = str(e)
+    eng = _SurfaceEngine.made[-1]
+    info = {"stdout": buf.getvalue(), "err": err, "device": eng.device, "comm": eng.comm, "n_f": eng.n_f, "n_u": eng.n_u,
+            "n_b": eng.n_b, "n_total": {k: v[-1] for k, v in eng.sets.items()},
+            "first_f": eng.sets["f"][0][0].tolist(), "first_u": eng.sets["u"][0][0].tolist(), "steps": eng.steps}
+    import json
+    with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
+        json.dump(info, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["burgers", "schrodinger"])
+def test_drop_in_scripts_shard_their_point_sets_over_the_ranks(tmp_path, which):
+    """`python -m torch.distributed.run --nproc-per-node 2 1d-burgers/inf_cont_burgers.py` (and the Schrodinger class):
+    device = LOCAL_RANK, each rank gets its contiguous block of the collocation / data / boundary sets with the GLOBAL
+    counts as denominators, the engine joins a 2-rank communicator without the bench's timing probe, rank 0 alone
+    prints the log, and fit() ends by checking that the replicas hold identical weights"""
+    import json
+    from pinn_native.parallel import shard_bounds
+    port = 29800 + (os.getpid() + len(which)) % 90
+    mp.spawn(_surface_worker, args=(2, port, str(tmp_path), which, None), nprocs=2, join=True)
+    out = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    n_f, n_u, n_b = (1001, 63, 0) if which == "burgers" else (2003, 51, 37)
+    for r, o in enumerate(out):
+        assert o["err"] == "" and o["device"] == r and o["comm"] == [2, r]
+        lo, hi = shard_bounds(n_f, 2, r)
+        assert o["n_f"] == hi - lo and o["n_total"]["f"] == n_f
+        lo, hi = shard_bounds(n_u, 2, r)
+        assert o["n_u"] == hi - lo and o["n_total"]["u"] == n_u
+        if n_b:
+            lo, hi = shard_bounds(n_b, 2, r)
+            assert o["n_b"] == hi - lo and o["n_total"]["b"] == n_b
+    assert out[0]["first_f"] != out[1]["first_f"] and out[0]["first_u"] != out[1]["first_u"]      # different blocks
+    assert out[0]["steps"] == out[1]["steps"] > 0
+    assert out[1]["stdout"] == ""
+    assert "Training started" in out[0]["stdout"] and "Training finished" in out[0]["stdout"]
+    assert ("nt_epoch =      5" in out[0]["stdout"]) == (which == "burgers")
+    if which == "schrodinger":
+        assert out[0]["stdout"].count("mse_0") == 6
+
+
+def test_fit_refuses_replicas_that_drifted_apart(tmp_path):
+    import json
+    port = 29890 + os.getpid() % 9
+    mp.spawn(_surface_worker, args=(2, port, str(tmp_path), "burgers", 1), nprocs=2, join=True)
+    out = [json.load(open(tmp_path / ("rank%d.json" % r))) for r in range(2)]
+    assert all("replicas hold different weights" in o["err"] for o in out), out

@@ -233,3 +233,76 @@ def test_oracle_ref_archive_holds_the_reference_files_verbatim(tmp_path):
         assert not os.path.exists(os.path.join(make_ref.DST, rel))      # no plain copy of a reference source in the tree
     # the archive never enters the history
     assert "oracle/_ref/" in open(os.path.join(ROOT, ".gitignore")).read()
+
+
+# ---- the L-BFGS restart guard of NeuralNetwork.nt_optimization (hp["nt_guard"]), scripted engine ---------------------------
+class _GuardEngine(object):
+    """lbfgs_run follows a script of per-chunk loss lists; records the calls the guard makes"""
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f32", device=0):
+        self.n_params, self.w, self.calls = 5, np.zeros(5), []
+        self.n_f = self.n_u = self.n_b = 0
+        self.script, self.it, self.left = [], 0, 0
+
+    def set_weights(self, w): self.w = np.array(w, dtype=np.float64); self.calls.append(("set_weights", self.w.copy()))
+    def get_weights(self): return self.w.copy()
+    def adam_init(self, *a): pass
+    def set_data(self, X, u, n_total=None): pass
+    def status(self): return 0, 0
+    def lbfgs_begin(self, n, *a): self.calls.append(("begin", n)); self.it, self.left = 0, n
+
+    def lbfgs_run(self, n):
+        losses = np.array(self.script.pop(0), dtype=np.float64)
+        its = np.arange(self.it + 1, self.it + 1 + len(losses), dtype=np.int32)
+        self.it += len(losses); self.left -= len(losses)
+        self.w = self.w + len(losses)                   # "weights" = iterations applied since the last set_weights
+        return its, losses, int(not self.script)
+
+
+def _guarded_model(monkeypatch, hp_extra, script):
+    for p in (os.path.join(ROOT, "pinns-tf2.0_amd", "utils"),):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import neuralnetwork
+    from logger import Logger
+    monkeypatch.setattr(neuralnetwork, "Engine", _GuardEngine)
+    hp = dict({"layers": [2, 1], "tf_epochs": 0, "tf_lr": 0.03, "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 40, "nt_lr": 0.8,
+               "nt_ncorr": 50, "log_frequency": 10}, **hp_extra)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        nn = neuralnetwork.NeuralNetwork(hp, Logger(hp), [1.0, 1.0], [-1.0, 0.0])
+        nn._engine.script = script
+        nn._engine.calls.clear()
+        nn.w_start = nn._engine.w.copy()
+        nn.nt_optimization(np.zeros((4, 2)), np.zeros((4, 1)))
+    lines = [l for l in buf.getvalue().splitlines() if l.startswith("nt_epoch")]
+    return nn, lines
+
+
+def test_nt_guard_discards_an_exploding_chunk_and_restarts_from_the_last_accepted_one(monkeypatch, capsys):
+    ok1 = list(np.linspace(1.0, 0.5, 10))
+    boom = [0.4, 0.3, 3.0e5, 1e9, 1e8, 1e7, 1e6, 1e5, 1e4, 1e3]          # iteration 13 jumps by 6 decades
+    ok2 = list(np.linspace(0.5, 0.3, 10))
+    ok3 = list(np.linspace(0.3, 0.2, 10))
+    ok4 = list(np.linspace(0.2, 0.1, 9))
+    nn, lines = _guarded_model(monkeypatch, {"dtype": "f32"}, [ok1, boom, ok2, ok3, ok4])
+    calls = nn._engine.calls
+    assert [c for c in calls if c[0] == "begin"] == [("begin", 40), ("begin", 30)]      # 30 iterations were left
+    restored = [c[1] for c in calls if c[0] == "set_weights"]
+    assert len(restored) == 1 and np.array_equal(restored[0], nn.w_start + 10.0)        # the weights after chunk 1
+    assert nn.nt_restarts == [(13, 10)]
+    assert [int(l.split()[2]) for l in lines] == [10, 20, 30]          # numbering continues; the discarded chunk is not logged
+    assert "nt_guard: loss 3.000e+05 at L-BFGS iteration 13" in capsys.readouterr().err
+
+
+def test_nt_guard_is_off_in_the_reference_arithmetic_and_bounded_when_on(monkeypatch):
+    boom = [0.4, 0.3, 3.0e5, float("nan"), 1e8, 1e7, 1e6, 1e5, 1e4, 1e3]
+    nn, lines = _guarded_model(monkeypatch, {"dtype": "f64"}, [list(np.ones(10)), boom, list(np.ones(10)), list(np.ones(9))])
+    assert nn._nt_guard == 0.0 and nn.nt_restarts == [] and [c for c in nn._engine.calls if c[0] == "begin"] == [("begin", 40)]
+    assert len(lines) == 3                                             # float64 = the reference: nothing is discarded
+    # on, and every retry explodes again: MAX_RESTARTS discards, then the run is left alone
+    script = [list(np.ones(10))] + [boom] * 5 + [boom, list(np.ones(10)), list(np.ones(9))]
+    nn, lines = _guarded_model(monkeypatch, {"dtype": "f32"}, script)
+    assert len(nn.nt_restarts) == nn.MAX_RESTARTS == 5 and len([c for c in nn._engine.calls if c[0] == "begin"]) == 6
+    nn, _ = _guarded_model(monkeypatch, {"dtype": "f64", "nt_guard": 100.0}, [list(np.ones(10)), [200.0] * 10, list(np.ones(10)), list(np.ones(10)), list(np.ones(9))])
+    assert nn.nt_restarts == [(11, 10)]                                # explicit hp key wins over the dtype default
