@@ -23,6 +23,11 @@ the product's default (hp["dtype"]); --dtype f32 swaps the roles.  Beside it the
                 (float64_leg under --dtype f32)
   cfg5_leg      BASELINE configs[4]: N_f = 10^6 in total, sharded over the N ranks (125k per GPU at N = 8); at N = 1
                 this is the steady-state (many tiles per CU) figure of the same kernel
+  cfg3_leg      BASELINE configs[2]: Burgers identification (1d-burgers/ide_cont_burgers.py:25-43), N_u = 10000 data points
+                carrying the residual, lambda_1 / lambda_2 trainable, Adam (lr 1e-3) : L-BFGS in the reference's 100 : 500
+  cfg4_leg      BASELINE configs[3]: Schrodinger (1dcomplex-schrodinger/inf_cont_schrodinger.py:19-41), 4x100 two-output
+                net, N_f = 20000, N_0 = N_b = 50, Adam (lr .05, beta_1 .99, eps .1) only, as the reference
+                (both in the headline's arithmetic, each with its own roofline, >= 1 s timed)
   final_l2_error{,_f64}   the reference's default schedule end to end in both arithmetics, beside the reference's own
                 ulp-perturbation ensemble (tests/golden/burgers_band.json)
   cpu_baseline  Tier A: the reference's own scripts (oracle/_ref) over the torch-CPU shim, timed on this host;
@@ -50,7 +55,14 @@ for p in (ROOT, PKG, os.path.join(PKG, "utils"), os.path.join(PKG, "1d-burgers")
         sys.path.insert(0, p)
 
 LAYERS = [2, 20, 20, 20, 20, 20, 20, 20, 20, 1]
-M_W = sum(a * b for a, b in zip(LAYERS[:-1], LAYERS[1:]))          # 2860 MACs per Taylor channel
+LAYERS_SCHRODINGER = [2, 100, 100, 100, 100, 2]
+
+
+def macs(layers):
+    return sum(a * b for a, b in zip(layers[:-1], layers[1:]))
+
+
+M_W = macs(LAYERS)                                                 # 2860 MACs per Taylor channel (Schrodinger: 30400)
 NU = 0.01 / np.pi
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}                          # MI355X_MICROARCH.md: vector = matrix FP32/FP64 peak
 HBM_PEAK_GBPS = 8000.0
@@ -58,26 +70,40 @@ MIN_TIMED_MS = float(os.environ.get("PINN_BENCH_MIN_TIMED_MS", "3000"))   # per 
 MAX_BLOCKS = 8000                                                         # 5-second GPU-busy sampler to see the legs
 KERNEL_NAMES = {2: "pinn::k_fused20m", 1: "pinn::k_fused20", 7: "pinn::k_fused20d", 0: "pinn::k_forward+k_backward",
                 3: "pinn::k_wide_fwd+k_wide_bwd"}
+BURGERS_ADAM = (0.03, 0.9, 0.999, 1e-7)                            # 1d-burgers/inf_cont_burgers.py:35-37 (eps None = Keras 1e-7)
+BURGERS_LBFGS = (0.8, 50)                                          # :39-41
 LAUNCH_FLOOR_US = 4.5                                              # a trivial launch on this stream
 
 
-def canonical_weights():
+def canonical_weights(layers=None, extra=()):
     from scipy.stats import truncnorm
+    layers = layers or LAYERS
     rs = np.random.RandomState(1234)
     parts = []
-    for fi, fo in zip(LAYERS[:-1], LAYERS[1:]):
+    for fi, fo in zip(layers[:-1], layers[1:]):
         sigma = np.sqrt(2.0 / (fi + fo)) / 0.87962566103423978
         parts.append((truncnorm.rvs(-2, 2, size=(fi, fo), random_state=rs) * sigma).ravel())
         parts.append(np.zeros(fo))
+    parts.append(np.asarray(extra, dtype=np.float64))
     return np.concatenate(parts)
 
 
-def make_engine(dtype, device, X_f, X_u, u, lb, ub, world, rank):
+def burgers_workload(data):
+    """BASELINE configs[1] / [4]: the sets of prep_data, nu, the reference's optimiser settings"""
+    X_f, X_u, u, lb, ub = data
+    return {"layers": LAYERS, "pde": "burgers", "lb": lb, "ub": ub, "sets": {"X_f": X_f, "X_u": X_u, "u": u},
+            "pde_params": (NU,), "adam": BURGERS_ADAM, "lbfgs": BURGERS_LBFGS, "points": len(X_f),
+            # SURVEY.md 8(d): 24 M_w per collocation point (4 Taylor channels x (forward + 2 x reverse) x 2 FLOP), 6 M_w per data point
+            "flops": lambda n: 24.0 * M_W * n["f"] + 6.0 * M_W * n["u"]}
+
+
+def make_engine(dtype, device, wl, world, rank):
     import pinn_native
     from pinn_native.parallel import attach_shards
-    eng = pinn_native.Engine(LAYERS, lb, ub, pde="burgers", dtype=dtype, device=device)
-    attach_shards(eng, world, rank, X_f=X_f, X_u=X_u, u=u)
-    eng.set_pde_params(NU)
+    eng = pinn_native.Engine(wl["layers"], wl["lb"], wl["ub"], pde=wl["pde"], dtype=dtype, device=device)
+    attach_shards(eng, world, rank, **wl["sets"])
+    if wl.get("pde_params"):
+        eng.set_pde_params(*wl["pde_params"])
     return eng
 
 
@@ -102,33 +128,34 @@ class World(object):
         return float(t[0])
 
 
-def reset(eng, w0):
+def reset(eng, w0, adam=BURGERS_ADAM):
     eng.set_weights(w0)
-    eng.adam_init(0.03, 0.9, 0.999, 1e-7)
+    eng.adam_init(*adam)
 
 
-def run_steps(eng, k_adam, k_lbfgs):
+def run_steps(eng, k_adam, k_lbfgs, lbfgs=BURGERS_LBFGS):
     """exactly k_adam + k_lbfgs optimiser iterations = as many loss+grad evaluations; -> L-BFGS done code"""
     done = 1
     if k_adam:
         eng.adam_run(k_adam, want_losses=False)
     if k_lbfgs:
-        eng.lbfgs_begin(k_lbfgs, 0.8, 50, float(np.finfo(float).eps))      # the initial evaluation
+        eng.lbfgs_begin(k_lbfgs, lbfgs[0], lbfgs[1], float(np.finfo(float).eps))      # the initial evaluation
         done = 0
         while not done:
             _, _, done = eng.lbfgs_run(k_lbfgs)
     return int(done)
 
 
-def time_blocks(eng, wd, w0, k_adam, k_lbfgs, min_ms=MIN_TIMED_MS, max_blocks=MAX_BLOCKS):
+def time_blocks(eng, wd, w0, k_adam, k_lbfgs, min_ms=MIN_TIMED_MS, max_blocks=MAX_BLOCKS, adam=BURGERS_ADAM,
+                lbfgs=BURGERS_LBFGS):
     """blocks of exactly K steps, barrier + sync on both sides, MAX over ranks; repeated until >= min_ms are timed.
     Every rank sees the same (max-reduced) block times, so every rank runs the same number of blocks."""
     times, done = [], 1
     while (sum(times) * 1e3 < min_ms and len(times) < max_blocks) or not times:
-        reset(eng, w0)
+        reset(eng, w0, adam)
         wd.barrier(eng)                                    # everybody starts together ...
         t0 = time.perf_counter()
-        done = run_steps(eng, k_adam, k_lbfgs)
+        done = run_steps(eng, k_adam, k_lbfgs, lbfgs)
         eng.sync()                                         # ... this rank's K steps are complete on its GPU ...
         dt = time.perf_counter() - t0
         times.append(wd.max(dt))                           # ... and the block lasts as long as the slowest rank
@@ -137,21 +164,22 @@ def time_blocks(eng, wd, w0, k_adam, k_lbfgs, min_ms=MIN_TIMED_MS, max_blocks=MA
     return times, done
 
 
-def kernel_samples(eng, w0, k_adam, k_lbfgs, want=32):
+def kernel_samples(eng, w0, k_adam, k_lbfgs, want=32, adam=BURGERS_ADAM, lbfgs=BURGERS_LBFGS):
     """the loss+grad kernel's own duration: HIP events attached to the launches (separate, untimed pass)"""
     evals = k_adam + k_lbfgs
     n_blocks = max(1, -(-want // max(evals, 1)))
     eng.timing_enable(n_blocks * (evals + 1), every=1)
     for _ in range(n_blocks):
-        reset(eng, w0)
-        run_steps(eng, k_adam, k_lbfgs)
+        reset(eng, w0, adam)
+        run_steps(eng, k_adam, k_lbfgs, lbfgs)
     tim = eng.timing_read()
     eng.timing_enable(0, 1)
     return tim
 
 
-def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None):
-    flops = 24.0 * M_W * n_f_local + 6.0 * M_W * n_u_local           # SURVEY.md 8(d): algorithmic FLOP per launch
+def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None, flops=None, n_b_local=0):
+    if flops is None:
+        flops = 24.0 * M_W * n_f_local + 6.0 * M_W * n_u_local       # SURVEY.md 8(d): algorithmic FLOP per launch
     kernel_ms = tim["fwd_ms"] if tim["kernel_exact"] else max(tim["sweeps_ms"] - tim["empty_bracket_ms"], 0.0)
     achieved = flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else None
     peak = PEAK_TFLOPS[dtype]
@@ -162,7 +190,7 @@ def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None):
     except Exception:
         pass
     n_cu = info.get("compute_units", 256)
-    tiles = (n_f_local + n_u_local + 63) // 64
+    tiles = (n_f_local + n_u_local + 2 * n_b_local + 63) // 64
     path = eng.kernel_path()
     single_kernel = path in (1, 2, 7)
     wgs = min(tiles, n_cu) if path in (2, 7) else tiles
@@ -173,7 +201,7 @@ def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None):
         "hbm_gbps": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
         "hbm_peak_gbps": HBM_PEAK_GBPS,
         "algorithmic_flop_per_launch": flops,
-        "algorithmic_hbm_bytes_per_launch": (4 if dtype == "f32" else 8) * 2 * (n_f_local + n_u_local),
+        "algorithmic_hbm_bytes_per_launch": (4 if dtype == "f32" else 8) * 2 * (n_f_local + n_u_local + 2 * n_b_local),
         "kernel": KERNEL_NAMES.get(path, "pinn::k_t16_fwd+k_t16_bwd"),
         "avg_launch_ms": kernel_ms, "launches_sampled": tim["n"],
         "avg_launch_method": "hipExtLaunchKernelGGL start/stop events on the engine's stream" if tim["kernel_exact"]
@@ -189,42 +217,53 @@ def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None):
 
 
 def leg(name, dtype, device, data, w0, wd, k_adam, k_lbfgs, warmup, kernel_path=-1, traffic=None, spin=True,
-        init_comm=None):
-    """one timed leg on one point set; -> (result dict, engine)"""
-    X_f, X_u, u, lb, ub = data
-    eng = make_engine(dtype, device, X_f, X_u, u, lb, ub, wd.world, wd.rank)
+        init_comm=None, min_ms=None):
+    """one timed leg on one workload (a dict as burgers_workload makes it, or the Burgers data tuple); -> (result dict, engine)"""
+    wl = data if isinstance(data, dict) else burgers_workload(data)
+    sets, adam, lbfgs = wl["sets"], wl["adam"], wl["lbfgs"] or BURGERS_LBFGS
+    if not wl["lbfgs"]:                                    # an Adam-only schedule (the reference's Schrodinger script)
+        k_adam, k_lbfgs = k_adam + k_lbfgs, 0
+    eng = make_engine(dtype, device, wl, wd.world, wd.rank)
     if kernel_path >= 0:
         eng.set_kernel_path(kernel_path)
     comm_mode = init_comm(eng) if init_comm else "none"
-    reset(eng, w0)
+    reset(eng, w0, adam)
+    n_pts = wl["points"]
     if warmup > 0:
         if spin:
             # a fresh box idles at a low clock: keep the GPU busy for a few tenths of a second first (untimed; a
             # fixed number of steps, not a time limit: with a communicator every rank must run the same evaluations)
-            eng.adam_run(max(200, int(6000 * 10000 / max(len(X_f), 1))), want_losses=False)
+            eng.adam_run(max(200, int(6000 * 10000 / max(n_pts, 1))), want_losses=False)
             eng.sync()
-            reset(eng, w0)
-        w_adam = max(warmup // 3, 1)
-        w_lbfgs = max(warmup - w_adam, 2)
+            reset(eng, w0, adam)
+        w_adam = max(warmup // 3, 1) if wl["lbfgs"] else warmup
         eng.adam_run(w_adam, want_losses=False)
-        eng.lbfgs_begin(max(k_lbfgs, w_lbfgs), 0.8, 50, float(np.finfo(float).eps))
-        eng.lbfgs_run(w_lbfgs)
-    times, done = time_blocks(eng, wd, w0, k_adam, k_lbfgs)
-    tim = kernel_samples(eng, w0, k_adam, k_lbfgs)
+        if wl["lbfgs"]:
+            w_lbfgs = max(warmup - w_adam, 2)
+            eng.lbfgs_begin(max(k_lbfgs, w_lbfgs), lbfgs[0], lbfgs[1], float(np.finfo(float).eps))
+            eng.lbfgs_run(w_lbfgs)
+    times, done = time_blocks(eng, wd, w0, k_adam, k_lbfgs, min_ms=MIN_TIMED_MS if min_ms is None else min_ms, adam=adam,
+                              lbfgs=lbfgs)
+    tim = kernel_samples(eng, w0, k_adam, k_lbfgs, adam=adam, lbfgs=lbfgs)
     from pinn_native.parallel import shard_bounds
-    lo, hi = shard_bounds(len(X_f), wd.world, 0)
-    ulo, uhi = shard_bounds(len(X_u), wd.world, 0)
+
+    def local(key):
+        lo, hi = shard_bounds(len(sets[key]), wd.world, 0) if key in sets else (0, 0)
+        return hi - lo
+    n_local = {"f": local("X_f"), "u": local("X_u"), "b": local("X_lb")}
     K = k_adam + k_lbfgs
     med = float(np.median(times))
     out = {
-        "name": name, "dtype": dtype, "n_f_total": int(len(X_f)), "n_f_per_gpu": hi - lo,
-        "value": len(X_f) * K / med if done == 1 else None, "unit": "collocation-points/s",
-        "ms_per_step": 1e3 * med / K, "steps_per_block": K, "blocks_timed": len(times),
+        "name": name, "dtype": dtype, "n_f_total": int(n_pts), "n_f_per_gpu": n_local["f"] or n_local["u"],
+        "value": n_pts * K / med if done == 1 else None, "unit": "collocation-points/s",
+        "ms_per_step": 1e3 * med / K, "steps_per_block": K, "adam_steps_per_block": k_adam, "lbfgs_steps_per_block": k_lbfgs,
+        "blocks_timed": len(times),
         "timed_ms_total": 1e3 * float(np.sum(times)), "ms_per_step_first_block": 1e3 * times[0] / K,
         "ms_per_step_min_block": 1e3 * float(np.min(times)) / K,
         "kernel_path": eng.kernel_path(), "lbfgs_done_code": done, "valid": done == 1,
         "allreduce": comm_mode, "allreduce_probe_us": getattr(eng, "comm_probe_us", None),
-        "roofline": roofline(eng, tim, dtype, hi - lo, uhi - ulo, traffic),
+        "roofline": roofline(eng, tim, dtype, n_local["f"], n_local["u"], traffic, flops=wl["flops"](n_local),
+                             n_b_local=n_local["b"]),
     }
     return out, eng
 
@@ -241,16 +280,19 @@ def final_error(eng, w0, X_star, u_star):
     return float(eng.error_l2(X_star, u_star))         # device-side reduction (pinn_error_l2)
 
 
-def reference_ensemble():
-    """the reference's own final errors under 1..k-ulp perturbations of the initial weights (make_band.py)"""
+def reference_ensemble(dtype="f64"):
+    """the reference's own final errors under perturbations of the initial weights (make_band.py): (1 + k 2^-52) for the
+    float64 engine, (1 + k 2^-23) -- the size of a float32 rounding -- for the float32 engine, as the tests judge them"""
+    name = "burgers_band.json" if dtype == "f64" else "burgers_band_eps32.json"
     try:
-        with open(os.path.join(ROOT, "tests", "golden", "burgers_band.json")) as fh:
+        with open(os.path.join(ROOT, "tests", "golden", name)) as fh:
             b = json.load(fh)
         errs = sorted(v["final_error"] for v in b["runs"].values())
         med = float(np.median(errs))
         return {"reference": b["reference_final_error"], "ensemble_min": errs[0], "ensemble_max": errs[-1],
                 "ensemble_median": med, "ensemble_radius": float(max(abs(e - med) for e in errs)),
-                "members": len(errs), "source": "tests/golden/burgers_band.json (reference over the shim, init x (1 + k 2^-52))"}
+                "members": len(errs), "source": "tests/golden/%s (reference over the shim, init x (1 + k 2^%d))" % (
+                    name, -52 if dtype == "f64" else -23)}
     except Exception:
         return None
 
@@ -306,32 +348,69 @@ def cpu_baseline_port(X_f, X_u, u, lb, ub, w0, budget_s=6.0):
                 n, X_f.shape[0], X_u.shape[0], dt)}
 
 
-def pmc_traffic(dtype, n_f_total, world, path):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
-    are collected in separate runs, so they cannot be read live here): the headline workload (N_f = 10000) and the
-    N_f = 10^6 leg on one GPU; null otherwise."""
-    if world != 1 or n_f_total not in (10000, 1000000):
-        return None
+def pmc_traffic(name, dtype, n_f_total, world, path):
+    """HBM bytes per launch of a leg's loss+gradient kernel(s) from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE are collected in separate runs under the profiler, profiles/pmc_eval.py, so they cannot be read live
+    here) -> (bytes or None, where the number comes from / why there is none).  An entry of profiles/pmc_traffic.json
+    applies only to the workload, arithmetic, kernel path and point count it was collected on, on one GPU."""
+    table = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if world != 1:
+        return None, "the counter passes were collected on one GPU; this run shards the points over %d" % world
     try:
-        name = "r03_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) else "r02_pmc_traffic.json"
-        with open(os.path.join(ROOT, "profiles", name)) as fh:
-            j = json.load(fh)
-        if j.get("kernel_path_" + dtype) != path:
-            return None
-        if n_f_total == 1000000:
-            return float(j["nf1e6"]["traffic_bytes_per_launch_" + dtype])
-        return float(j["traffic_bytes_per_launch" if dtype == "f32" else "traffic_bytes_per_launch_f64"])
-    except Exception:
-        return None
+        with open(table) as fh:
+            entries = json.load(fh)["entries"]
+    except Exception as e:
+        return None, "profiles/pmc_traffic.json unreadable: %s" % e
+    for e in entries:
+        if (e["leg"], e["dtype"], e["kernel_path"], e["points"]) == (name, dtype, path, n_f_total):
+            return float(e["traffic_bytes_per_launch"]), "profiles/pmc_traffic.json <- %s" % e["source"]
+    return None, ("no counter pass was collected for leg %s, %s, kernel path %d, %d points (profiles/pmc_traffic.json)"
+                  % (name, dtype, path, n_f_total))
 
 
-def with_traffic(leg_dict, world):
+def with_traffic(leg_dict, world, name=None):
     """attach the PMC traffic (and the HBM rate it implies) to a leg's roofline"""
     rf = leg_dict["roofline"]
-    rf["traffic"] = pmc_traffic(leg_dict["dtype"], leg_dict["n_f_total"], world, leg_dict["kernel_path"])
+    key = name or {"float32": "headline", "float64": "headline"}.get(leg_dict["name"], leg_dict["name"])
+    rf["traffic"], rf["traffic_source"] = pmc_traffic(key, leg_dict["dtype"], leg_dict["n_f_total"], world,
+                                                      leg_dict["kernel_path"])
     if rf["traffic"] and rf["avg_launch_ms"]:
         rf["hbm_gbps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
     return leg_dict
+
+
+def identification_workload():
+    """BASELINE configs[2] (1d-burgers/ide_cont_burgers.py:25-43): prep_data's identification branch with
+    N_u = 10000 samples of the full field (they carry data misfit AND residual), lambda = (0, -6) appended to the
+    canonical weights, Adam lr 1e-3, L-BFGS lr .8 / 50 pairs; the reference runs 100 : 500 iterations"""
+    import burgersutil
+    np.random.seed(1234)
+    r = burgersutil.prep_data(os.path.join(PKG, "1d-burgers", "data", "burgers_shock.mat"), 10000, noise=0.0)
+    X_u, u, ub, lb = r[7], r[8], r[9], r[10]
+    return {"layers": LAYERS, "pde": "burgers_ide", "lb": lb, "ub": ub, "sets": {"X_u": X_u, "u": u}, "pde_params": None,
+            "adam": (0.001, 0.9, 0.999, 1e-7), "lbfgs": (0.8, 50), "points": len(X_u), "adam_share": 1.0 / 6.0,
+            "w0": canonical_weights(LAYERS, extra=(0.0, -6.0)),
+            # every data point goes through the full Taylor forward and reverse sweep: 24 M_w, like a collocation point
+            "flops": lambda n: 24.0 * M_W * n["u"]}
+
+
+def schrodinger_workload():
+    """BASELINE configs[3] (1dcomplex-schrodinger/inf_cont_schrodinger.py:19-41): 2-100-100-100-100-2, N_0 = N_b = 50,
+    N_f = 20000, Adam lr .05 / beta_1 .99 / eps .1, no L-BFGS; X0 = (x0, 0) as the evident intent of the driver"""
+    sys.path.insert(0, os.path.join(PKG, "1dcomplex-schrodinger"))
+    import schrodingerutil
+    np.random.seed(1234)
+    r = schrodingerutil.prep_data(os.path.join(PKG, "1dcomplex-schrodinger", "data", "NLS.mat"), 50, 50, 20000, noise=0.0)
+    X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
+    m_w = macs(LAYERS_SCHRODINGER)
+    return {"layers": LAYERS_SCHRODINGER, "pde": "schrodinger", "lb": lb, "ub": ub,
+            "sets": {"X_f": X_f, "X_u": X0, "u": np.concatenate([u0, v0], 1),
+                     "X_lb": np.concatenate((0 * tb + lb[0], tb), 1), "X_ub": np.concatenate((0 * tb + ub[0], tb), 1)},
+            "pde_params": None, "adam": (0.05, 0.99, 0.999, 0.1), "lbfgs": None, "points": len(X_f),
+            "w0": canonical_weights(LAYERS_SCHRODINGER),
+            # collocation 24 M_w; initial-data points value channel only (6 M_w); the 2 x N_b boundary points carry
+            # value and x-derivative (two of the four channels: 12 M_w)
+            "flops": lambda n: m_w * (24.0 * n["f"] + 6.0 * n["u"] + 12.0 * 2 * n["b"])}
 
 
 def main():
@@ -352,6 +431,8 @@ def main():
     ap.add_argument("--no-f64-leg", "--no-other-leg", dest="no_f64_leg", action="store_true",
                     help="skip the leg in the other arithmetic (float32_leg under --dtype f64, float64_leg under f32)")
     ap.add_argument("--no-cfg5-leg", action="store_true", help="skip the N_f = 10^6 leg (BASELINE configs[4])")
+    ap.add_argument("--no-cfg34-legs", action="store_true",
+                    help="skip the identification (BASELINE configs[2]) and Schrodinger (configs[3]) legs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -439,6 +520,26 @@ def main():
                         "N = 1 line, allreduce_probe_us = one [P+4] float64 exchange on this node")
         e5.close()
 
+    # ---- cfg 3 / cfg 4: the other two single-GPU configurations of BASELINE.json, in the headline's arithmetic -------------
+    cfg3 = cfg4 = None
+    if not args.no_cfg34_legs and not weak:
+        for tag, make in (("cfg3", identification_workload), ("cfg4", schrodinger_workload)):
+            wl = make()
+            ka = max(1, int(round(args.steps * wl.get("adam_share", 1.0 / 3.0)))) if wl["lbfgs"] else args.steps
+            lg, e = leg(tag, args.dtype, device, wl, wl["w0"], wd, ka, args.steps - ka, min(args.warmup, 6), spin=False,
+                        init_comm=init_comm, min_ms=MIN_TIMED_MS / 3.0)
+            with_traffic(lg, world)
+            lg["schedule"] = ("%d Adam + %d L-BFGS iterations per block" % (lg["adam_steps_per_block"], lg["lbfgs_steps_per_block"]))
+            e.close()
+            if tag == "cfg3":
+                cfg3 = lg
+                lg["note"] = ("BASELINE configs[2]: identification, N_u = 10000 data points carrying misfit and residual, "
+                              "lambda_1 / lambda_2 trainable (P = 3023); value = data points per second")
+            else:
+                cfg4 = lg
+                lg["note"] = ("BASELINE configs[3]: Schrodinger 2-100x4-2 (P = 30802), N_f = 20000, N_0 = N_b = 50, Adam only; "
+                              "roofline on the forward + reverse sweep pair (729600 FLOP per collocation point)")
+
     # every rank empties its C stdio buffer (RCCL's banner) before rank 0 prints: the JSON line stays the last line
     def flush_c():
         try:
@@ -451,7 +552,8 @@ def main():
     if dist is not None:
         dist.barrier()
     if rank == 0:
-        ens = reference_ensemble()
+        ens = reference_ensemble("f64")
+        ens_of = {"f64": ens, "f32": reference_ensemble("f32")}      # each arithmetic against the ensemble the tests use for it
 
         def delta(v):
             return abs(v - ens["reference"]) if (v is not None and ens) else None
@@ -479,16 +581,17 @@ def main():
             "valid": main_leg["valid"],
             "roofline": main_leg["roofline"],
             ("float32_leg" if other == "f32" else "float64_leg"): other_leg,
-            "cfg5_leg": cfg5,
+            "cfg5_leg": cfg5, "cfg3_leg": cfg3, "cfg4_leg": cfg4,
             "final_l2_error": errs.get(args.dtype), "final_l2_error_f64": errs.get("f64"),
             "final_l2_error_f32": errs.get("f32"),
-            "final_l2_error_reference": ens,
+            "final_l2_error_reference": ens, "final_l2_error_reference_f32": ens_of["f32"],
             # north_star's literal criterion, per arithmetic: |final error - the reference's k = 0 run| (<= 1e-3 asked;
             # the reference's own runs differ by more than that between two hosts)
             "final_l2_error_abs_delta": delta(errs.get(args.dtype)), "final_l2_error_abs_delta_f64": delta(errs.get("f64")),
             "final_l2_error_abs_delta_f32": delta(errs.get("f32")),
             "final_l2_error_within_1e-3": {k: (delta(v) is not None and delta(v) <= 1e-3) for k, v in errs.items()},
-            "final_l2_error_inside_reference_ensemble": {k: (ens is not None and ens["ensemble_min"] <= v <= ens["ensemble_max"])
+            "final_l2_error_inside_reference_ensemble": {k: (ens_of[k] is not None and
+                                                             ens_of[k]["ensemble_min"] <= v <= ens_of[k]["ensemble_max"])
                                                          for k, v in errs.items()},
             "final_l2_error_schedule": "100 Adam (lr .03) + 200 L-BFGS (lr .8, m=50), reference defaults, on the "
                                        "reference set N_f=10000 (sharded over the ranks)",

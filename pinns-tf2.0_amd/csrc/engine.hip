@@ -172,12 +172,6 @@ struct pinn_ctx {
   // compact (Gram-matrix) mode
   int lb_mode = 1, lb_mode_active = 0, lb_M1 = 0;
   double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
-  // single-GPU fused tail (k_lbc_reduce_dots): partial dot products per 64-column tile of the gradient vector
-  double* lb_pd = nullptr;
-  int lb_pd_cap = 0;                 // doubles allocated
-  bool lb_fuse_ok = false;           // this run may fuse (mode 1, one GPU, <= LBP_MAXTILES tiles, PINN_LBFGS_FUSE != 0)
-  bool lb_fuse_eval = false;         // the evaluation being issued belongs to an L-BFGS iteration: fuse its reduction
-  bool lb_pd_ready = false;          // lb_pd holds the dot products of the latest evaluation
   LbcExtra* lb_ex = nullptr;
 
   // collocation set generated on the device (pinn_lhs_collocation) instead of handed over
@@ -385,8 +379,6 @@ static int ensure_sets(pinn_ctx* c) {
 #if defined(PINN_ABL) && PINN_ABL == 8
   if (c->path == 2) c->n_wg = (n_pad / 64 < 2 * c->n_cu) ? n_pad / 64 : 2 * c->n_cu;   // ablation: two workgroups per CU
 #endif
-  if (c->path == 7) c->n_wg = fused20d_plan(n_pad, c->n_cu).n_wg;   // ... or 48-point tiles with a helper wave
-  if (c->path == 2) c->n_wg = fused20m_plan(c->nd.n_hidden, n_pad, c->n_cu).n_wg;   // ... or two workgroups per CU (k_fused20r)
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
   const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : (c->path == 2 || c->path == 7) ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
   const bool no_stash = c->path == 2 || c->path == 7;
@@ -430,15 +422,6 @@ static int launch_reduce(pinn_ctx* c, int n_rows, const AdamFuse* af) {
                          (real*)nullptr, (double*)nullptr, (double*)nullptr, 0.0, 0.0, 0.0, 0.0, (double*)nullptr,
                          c->nd, (float*)nullptr);
     HIPCHK(hipGetLastError());
-    return 0;
-  }
-  if (c->lb_fuse_eval && !af) {   // L-BFGS iteration on one GPU: the dot products ride on the reduction
-    hipLaunchKernelGGL((k_lbc_reduce_dots<real>), rgrid, dim3(RED_THREADS), lbc_reduce_dots_lds_bytes(), c->stream,
-                       (const real*)c->part, n_rows, c->R, c->gl, c->nd.n_theta, c->lb_M1,
-                       (const LbfgsState*)(c->lb_state + c->lb_flip), (const double*)c->lb_gold, (const double*)c->lb_d,
-                       c->lb_S, c->lb_Y, c->lb_pd, c->n_evals, c->d_nonfinite);
-    HIPCHK(hipGetLastError());
-    c->lb_pd_ready = true;
     return 0;
   }
   if (af)
@@ -533,18 +516,13 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
     if constexpr (sizeof(real) == 8 && PDE != 2)
       rc = fused20d_launch_any(PDE, c->nd, sd, (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts,
                                (const double*)c->tgt, (double)lbx, (double)lbt, (double)sx, (double)st,
-                               (double)c->nu, (double*)c->part, c->R, fused20d_plan(sd.n_pad, c->n_cu), c->row_index,
+                               (double)c->nu, (double*)c->part, c->R, c->n_wg, c->row_index,
                                c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
     if (rc) return fail(PINN_EHIP, "fused20d launch failed: %s", hipGetErrorString((hipError_t)rc));
   } else if (c->path == 2) {
     int rc = hipErrorInvalidValue;
     if constexpr (sizeof(real) == 4 && PDE != 2) {
-      if (fused20m_plan(c->nd.n_hidden, sd.n_pad, c->n_cu).recompute)      // throughput regime: kernels_fused20r.h
-        rc = fused20r_launch_any(PDE, c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
-                                 (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
-                                 (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
-                                 c->stream, c->stamps, ev4 ? ev4[0] : nullptr, ev4 ? ev4[1] : nullptr);
-      else if (c->nd.n_hidden == 8)
+      if (c->nd.n_hidden == 8)
         rc = fused20m_launch<PDE, 8>(c->nd, sd, (const float*)c->theta_r, c->img, (const float*)c->xs,
                                      (const float*)c->ts, (const float*)c->tgt, (float)lbx, (float)lbt,
                                      (float)sx, (float)st, (float)c->nu, (float*)c->part, c->R, c->n_wg,
@@ -768,7 +746,6 @@ static int eval_loss_grad(pinn_ctx* c, const AdamFuse* af = nullptr) {
   int rc = is_disc(c) ? disc_ensure(c) : ensure_sets(c);
   if (rc) return rc;
   c->n_evals += 1;
-  if (!c->lb_fuse_eval) c->lb_pd_ready = false;      // any other evaluation overwrites gl: its dot products are not in lb_pd
   hipEvent_t* ev4 = nullptr;
   if (c->timing && c->ev_used < c->ev_cap_evals && (c->ev_seen++ % c->ev_every) == 0)
     ev4 = &c->ev[(size_t)4 * c->ev_used];
@@ -1080,7 +1057,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   }
   if (fused_regs_ok(c)) nd.img_kind = 1;
   if (fused_f64_ok(c)) {
-    std::vector<int> ri((size_t)fused20d_blocks(nd.n_hidden) * 16 * 2);   // + the slot table of k_fused20dh
+    std::vector<int> ri((size_t)fused20d_blocks(nd.n_hidden) * 16);
     fused20d_row_index(nd, nd.n_hidden, ri.data());
     if (dev_alloc(&c->row_index, ri.size() * sizeof(int))) { delete c; return PINN_EHIP; }
     HIPCHK(hipMemcpy(c->row_index, ri.data(), ri.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1111,7 +1088,7 @@ int pinn_destroy(pinn_ctx* c) {
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp,
-                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite, c->lb_pd};
+                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
   if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
@@ -1326,31 +1303,8 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   c->lb_mode_active = (c->lb_mode == 1 && M1 <= LBC_MAXSLOTS) ? 1 : 0;
   if (c->lb_mode_active && lbc_coef_apply_lds_bytes(M1) > 64 * 1024) {
     const int lds = (int)lbc_coef_apply_lds_bytes(M1);
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  }
-  {
-    // OPT-IN (PINN_LBFGS_FUSE=1, read per run): the two-launch tail is parity-green and measured no faster than the
-    // three-launch one (f64 iteration 54.67 vs 54.54 us, profiles/r03_lbfgs_tail.txt): what k_lbc_dots costs is paid
-    // back by the 240 extra loads per workgroup with which k_lbc_coef_apply sums the partial sets
-    const char* fe = getenv("PINN_LBFGS_FUSE");
-    const bool fuse_env = fe && fe[0] == '1';
-    const int tiles = (c->R + RED_COLS - 1) / RED_COLS;
-    c->lb_fuse_ok = fuse_env && c->lb_mode_active && !c->comm && !c->xg.on && tiles <= LBP_MAXTILES;
-    c->lb_fuse_eval = false; c->lb_pd_ready = false;
-    if (c->lb_fuse_ok) {
-      const int need = tiles * lbc_nd(M1);
-      if (need > c->lb_pd_cap) {
-        if (dev_alloc(&c->lb_pd, (size_t)need * 8)) return PINN_EHIP;
-        c->lb_pd_cap = need;
-      }
-      HIPCHK(hipFuncSetAttribute((const void*)k_lbc_reduce_dots<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lbc_reduce_dots_lds_bytes()));
-      HIPCHK(hipFuncSetAttribute((const void*)k_lbc_reduce_dots<double>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lbc_reduce_dots_lds_bytes()));
-    }
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIPCHK(hipFuncSetAttribute((const void*)k_lbc_coef_apply<double>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
   if (n_corr > c->lb_cap_corr) {
     if (dev_alloc(&c->lb_S, (size_t)M1 * ring_ld((int)n) * 8) || dev_alloc(&c->lb_Y, (size_t)M1 * ring_ld((int)n) * 8) ||
@@ -1425,25 +1379,20 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
       // dot products of this iteration: already formed behind the evaluation's reduction (one partial set per
       // 64-column tile; opt-in), or by k_lbc_dots (two half sets, one when n > 4096) -- also N > 1 ranks, the first iteration after pinn_lbfgs_begin,
       // an evaluation issued by somebody else in between
-      const double* pd = c->lb_pd;
-      int n_part = (c->R + RED_COLS - 1) / RED_COLS;
-      const bool from_tiles = c->lb_pd_ready;
-      if (!from_tiles) {
-        if (n <= 2 * 2 * LBD_THREADS) {                 // two workgroups per ring slot, one pair stride each
-          hipLaunchKernelGGL(k_lbc_dots<2>, dim3(M1, 2), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
-                             c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
-          n_part = 2;
-        } else {
-          hipLaunchKernelGGL(k_lbc_dots<1>, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
-                             c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
-          n_part = 1;
-        }
-        pd = c->lb_dots;
+      int n_part;
+      if (n <= 2 * 2 * LBD_THREADS) {                 // two workgroups per ring slot, one pair stride each
+        hipLaunchKernelGGL(k_lbc_dots<2>, dim3(M1, 2), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
+                           c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+        n_part = 2;
+      } else {
+        hipLaunchKernelGGL(k_lbc_dots<1>, dim3(M1), dim3(LBD_THREADS), 0, c->stream, n, M1, st_in,
+                           c->gl, c->lb_gold, c->lb_d, c->lb_S, c->lb_Y, c->lb_dots);
+        n_part = 1;
       }
-      c->lb_pd_ready = false;
+      const double* pd = c->lb_dots;
       const dim3 agrid((n + 63) / 64);
-#define COEF_APPLY(REAL, PARTS)                                                                    \
-      hipLaunchKernelGGL((k_lbc_coef_apply<REAL, PARTS>), agrid, dim3(LBC_THREADS), lsh, c->stream, n, M1,   \
+#define COEF_APPLY(REAL)                                                                           \
+      hipLaunchKernelGGL((k_lbc_coef_apply<REAL>), agrid, dim3(LBC_THREADS), lsh, c->stream, n, M1,   \
                          c->lb_ncorr, c->lb_max_iter, c->lb_lr, c->lb_tol_x, c->lb_tol_fun,           \
                          c->lb_max_eval, c->lb_post_pending ? 1 : 0, n, st_in, st_out, c->gl,         \
                          pd, n_part, c->lb_SY + c->lb_flip * mm, c->lb_YY + c->lb_flip * mm,          \
@@ -1451,8 +1400,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
                          c->lb_YY + (c->lb_flip ^ 1) * mm, c->lb_ro + (c->lb_flip ^ 1) * M1,          \
                          c->lb_log_iter, c->lb_log_loss, c->lb_S, c->lb_Y, c->lb_d, c->lb_gold,       \
                          c->lb_x, c->theta, (REAL*)c->theta_r, c->nd, c->img)
-      if (from_tiles) { if (c->dtype == PINN_F64) COEF_APPLY(double, true); else COEF_APPLY(float, true); }
-      else { if (c->dtype == PINN_F64) COEF_APPLY(double, false); else COEF_APPLY(float, false); }
+      if (c->dtype == PINN_F64) COEF_APPLY(double); else COEF_APPLY(float);
 #undef COEF_APPLY
       c->lb_post_pending = false;
       c->lb_flip ^= 1;
@@ -1461,10 +1409,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     else
       hipLaunchKernelGGL((k_lbfgs_step<float>), dim3(1), dim3(LB_THREADS), 0, c->stream, n, c->lb_max_iter, c->lb_ncorr, c->lb_lr, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_x, c->theta, (float*)c->theta_r, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al, c->lb_q, c->nd, c->img);
     if (c->lb_iters_issued == c->lb_max_iter) break;              // last iteration: no re-evaluation
-    c->lb_fuse_eval = c->lb_fuse_ok && c->lb_mode_active;
-    int rc = eval_loss_grad(c);
-    c->lb_fuse_eval = false;
-    if (rc) return rc;
+    if (int rc = eval_loss_grad(c)) return rc;
     if (c->lb_mode_active) { c->lb_post_pending = true; continue; }   // folded into the next k_lbc_coef
     hipLaunchKernelGGL(k_lbfgs_post, dim3(1), dim3(LB_THREADS), 0, c->stream, n, n, c->lb_max_iter,
                        c->lb_max_eval, c->lb_tol_fun, c->lb_tol_x, c->lb_state + c->lb_flip, c->gl, c->lb_d,

@@ -18,23 +18,15 @@ inline size_t fused20d_lds_bytes(int n_hidden, int n_theta) {
 }
 
 // entry e = 16 * block + 4 * i + j of a wave's block list -> flat parameter index (reference layout), -1 = padding;
-// out holds 2 x fused20d_blocks(H) x 16 ints: behind the parameter indices the LDS slot table of k_fused20dh
+// out holds fused20d_blocks(H) x 16 ints
 void fused20d_row_index(const NetDesc& nd, int H, int* out);
 
 inline bool fused20d_depth_ok(int n_hidden) { return n_hidden == 4 || n_hidden == 6 || n_hidden == 8; }
-// Launch plan of path 7 for a set of n_pad points on n_cu compute units: k_fused20d on 64-point tiles, persistent over
-// min(tiles, CUs) workgroups.  With PINN_F64_HELPER=1 in the environment, launches that are one tile deep even with
-// 48-point tiles run the experimental k_fused20dh instead (three 16-point waves + a helper wave that takes 3/5 of their
-// weight-gradient blocks, kernels_fused20dh.h: built, parity-green, measured no faster -- kept for the record and the
-// test that pins it).  n_wg = workgroups = partial gradient rows.
-struct Fused20dPlan { int n_wg; int helper; };
-Fused20dPlan fused20d_plan(int n_pad, int n_cu);
-
+// Launch plan of path 7: 64-point tiles, persistent over n_wg = min(tiles, CUs) workgroups = partial gradient rows.
 // one loss+gradient evaluation (pde 0: Burgers inference, 1: identification; 4, 6 or 8 hidden layers); returns a hipError_t
 int fused20d_launch_any(int pde, const NetDesc& nd, const SetDesc& sd, const double* th, const double* xs,
                         const double* ts, const double* tgt, double lbx, double lbt, double sx, double st, double nu,
-                        double* part, int R, Fused20dPlan plan, const int* row_index, hipStream_t stream,
+                        double* part, int R, int n_wg, const int* row_index, hipStream_t stream,
                         long long* stamps, hipEvent_t ev_start, hipEvent_t ev_stop);
-size_t fused20d_plan_lds_bytes(Fused20dPlan plan, int n_hidden, int n_theta);
 
 }  // namespace pinn

@@ -17,16 +17,4 @@ int fused20m_launch_depth(int pde, const NetDesc& nd, const SetDesc& sd, const f
                           float nu, float* part, int R, int n_wg, hipStream_t stream, long long* stamps,
                           hipEvent_t ev_start, hipEvent_t ev_stop);
 
-// Launch plan of path 2 for n_pad points on n_cu compute units: k_fused20m (one workgroup per CU, full register stash);
-// with PINN_F32_RECOMPUTE=1 in the environment, 8 hidden layers and more tiles than CUs: the experimental k_fused20r
-// (kernels_fused20r.h: even layers stashed, odd layers recomputed, two workgroups per CU -- built, parity-green,
-// measured slower because of register spills; kept for the record and the test that pins it).
-// n_wg = workgroups = partial gradient rows.
-struct Fused20mPlan { int n_wg; int recompute; };
-Fused20mPlan fused20m_plan(int n_hidden, int n_pad, int n_cu);
-int fused20r_launch_any(int pde, const NetDesc& nd, const SetDesc& sd, const float* th, const float* img,
-                        const float* xs, const float* ts, const float* tgt, float lbx, float lbt, float sx, float st,
-                        float nu, float* part, int R, int n_wg, hipStream_t stream, long long* stamps,
-                        hipEvent_t ev_start, hipEvent_t ev_stop);
-
 }  // namespace pinn

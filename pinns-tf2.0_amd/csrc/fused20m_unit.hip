@@ -1,10 +1,7 @@
 // fused20m_unit.hip -- k_fused20m at hidden depths 4, 6 and 10 (see fused20m_api.h).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fPIC -c fused20m_unit.hip
 #include "kernels_fused20m.h"
-#include "kernels_fused20r.h"
 #include "fused20m_api.h"
-
-#include <cstdlib>
 
 namespace pinn {
 
@@ -31,29 +28,6 @@ int fused20m_launch_depth(int pde, const NetDesc& nd, const SetDesc& sd, const f
     default: return (int)hipErrorInvalidValue;
   }
 #undef ARGS
-}
-
-Fused20mPlan fused20m_plan(int n_hidden, int n_pad, int n_cu) {
-  static const int forced = [] { const char* e = getenv("PINN_F32_RECOMPUTE"); return e ? (e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1) : -1; }();
-  const int tiles = n_pad / 64;
-  // OPT-IN (PINN_F32_RECOMPUTE=1): parity-green, and measured SLOWER than k_fused20m (N_f = 10^6: 1576 vs 1308 us per
-  // Adam step, profiles/r03_fused20r.txt) -- hipcc splits the 256 registers of a wave 128 / 128 and the kernel carries
-  // 772 B of scratch per lane; the prize if the registers can be made to fit is 842 us (profiles/r03_ablate_two_wg.txt)
-  const bool rc = n_hidden == 8 && forced == 1 && tiles > n_cu;
-  if (rc) return Fused20mPlan{tiles < 2 * n_cu ? tiles : 2 * n_cu, 1};
-  return Fused20mPlan{tiles < n_cu ? tiles : n_cu, 0};
-}
-
-int fused20r_launch_any(int pde, const NetDesc& nd, const SetDesc& sd, const float* th, const float* img,
-                        const float* xs, const float* ts, const float* tgt, float lbx, float lbt, float sx, float st,
-                        float nu, float* part, int R, int n_wg, hipStream_t stream, long long* stamps,
-                        hipEvent_t ev_start, hipEvent_t ev_stop) {
-  if (nd.n_hidden != 8) return (int)hipErrorInvalidValue;
-  if (pde == 1)
-    return fused20r_launch<1, 8>(nd, sd, th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_wg, stream, stamps,
-                                 ev_start, ev_stop);
-  return fused20r_launch<0, 8>(nd, sd, th, img, xs, ts, tgt, lbx, lbt, sx, st, nu, part, R, n_wg, stream, stamps,
-                               ev_start, ev_stop);
 }
 
 }  // namespace pinn

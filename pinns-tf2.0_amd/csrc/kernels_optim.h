@@ -477,104 +477,6 @@ __global__ __launch_bounds__(LBD_THREADS) void k_lbc_dots(
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// ---------------------------------------------------------------------------------------------
-// k_lbc_reduce_dots (single GPU, n_theta + 3 <= 64 x LBP_MAXTILES): the row reduction of an evaluation AND the dot
-// products of the L-BFGS iteration that follows it, in one launch -- the iteration's tail is two launches
-// (this one, k_lbc_coef_apply) instead of three.  Every launch of the tail starts with a cold L2 (the acquire at a
-// kernel boundary) and pays one ~1.5 us round of global reads plus ~1 us of boundary whatever its size: k_lbc_dots
-// was 5.6 us for 2.4 MB of reads and 30 kflop.
-// Work split: workgroup = 64 gradient columns (as k_reduce_rows: 16 row slices, same summation order, so gl is
-// bit-identical to k_reduce_rows'); the workgroup then holds g, y_c = g - g_old, s_c = t d for its 64 elements and
-// the [slot][element] tile of both history rings (loaded in the same round as the rows), and forms the PARTIAL dot
-// products over its 64 elements: 5 per slot + 5 scalars -> pd[tile][lbc_nd(M1)], same layout as k_lbc_dots' `dots`.
-// k_lbc_coef_apply sums the tiles in index order.  Thread (group, kind, slot) sums a third of the elements, the
-// thirds are combined in index order: a fixed association, bit-reproducible; it differs from k_lbc_dots' (one
-// workgroup per slot, strided) at the 1e-16 level.  The candidate slot is staged with the new pair, so its entries
-// are y_c.s_c, y_c.y_c, s_c.g, y_c.g as k_lbc_dots has them.
-// ---------------------------------------------------------------------------------------------
-constexpr int LBP_MAXTILES = 64;
-constexpr int LBP_LD = 65;                        // tile row stride (doubles): slot-major, conflict-free element walks
-constexpr int LBP_PQ = 328;                       // 5 x 64 per-slot entries + 5 scalars (+3 pad) per element third
-__host__ __device__ inline int lbc_nd(int M1) { return 5 * M1 + LBC_NSCAL; }
-inline size_t lbc_reduce_dots_lds_bytes() {
-  return (size_t)(RED_SLICES * RED_COLS + 2 * 64 * LBP_LD + 3 * 64 + 3 * LBP_PQ) * 8;
-}
-
-template <typename real>
-__global__ __launch_bounds__(RED_THREADS) void k_lbc_reduce_dots(
-    const real* __restrict__ part, int n_rows, int R, double* __restrict__ gl, int n, int M1,
-    const LbfgsState* __restrict__ st, const double* __restrict__ g_old, const double* __restrict__ d,
-    double* __restrict__ Sh, double* __restrict__ Yh, double* __restrict__ pd, unsigned long long eval_no,
-    unsigned long long* __restrict__ nonfinite) {
-  extern __shared__ double lsh[];
-  double (*sh)[RED_COLS] = reinterpret_cast<double (*)[RED_COLS]>(lsh);
-  double* const tS = lsh + RED_SLICES * RED_COLS;
-  double* const tY = tS + 64 * LBP_LD;
-  double* const vG = tY + 64 * LBP_LD;
-  double* const vY = vG + 64;
-  double* const vS = vY + 64;
-  double* const pp = vS + 64;
-  const int tid = threadIdx.x, lane = tid & 63, q = uni(tid >> 6);
-  const int c = blockIdx.x * RED_COLS + lane;
-  const bool el = c < n;
-  // one round of global reads: the state, this element's g_old and d, four ring slots per wave -- and the rows
-  const int done0 = uni(st->done), head = uni(st->hist_head), len = uni(st->hist_len), n_it = uni(st->n_iter);
-  const double t = st->t;
-  const double go = el ? g_old[c] : 0.0, dv = el ? d[c] : 0.0;
-  double sv[4], yv[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int a = q + 16 * u;
-    const bool ok = el && a < M1;
-    sv[u] = ok ? Sh[(size_t)a * ring_ld(n) + c] : 0.0;
-    yv[u] = ok ? Yh[(size_t)a * ring_ld(n) + c] : 0.0;
-  }
-  const double g = reduce_column(part, n_rows, R, c, q, sh);
-  if (q == 0 && c < R) { gl[c] = g; note_nonfinite(g, c, n, eval_no, nonfinite); }
-  if (done0) return;
-  const bool first = (n_it == 0);
-  int cs = head + len; if (cs >= M1) cs -= M1;
-  if (q == 0) {
-    const double gi = el ? g : 0.0;
-    const double yc = (first || !el) ? 0.0 : gi - go, sc = (first || !el) ? 0.0 : dv * t;
-    vG[lane] = gi; vY[lane] = yc; vS[lane] = sc;
-    if (!first && el) { Sh[(size_t)cs * ring_ld(n) + c] = sc; Yh[(size_t)cs * ring_ld(n) + c] = yc; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int a = q + 16 * u;
-    if (a < M1) {
-      tS[a * LBP_LD + lane] = (a == cs) ? vS[lane] : sv[u];
-      tY[a * LBP_LD + lane] = (a == cs) ? vY[lane] : yv[u];
-    }
-  }
-  __syncthreads();
-  double* __restrict__ out = pd + (size_t)blockIdx.x * lbc_nd(M1);
-  if (q < 15) {
-    const int grp = q / 5, k = q - 5 * grp;                      // wave-uniform: element third, kind of product
-    const double* __restrict__ X = ((k == 0 || k == 3) ? tS : tY) + (lane < M1 ? lane : 0) * LBP_LD;
-    const double* __restrict__ V = (k == 0 || k == 2) ? vY : (k == 1 ? vS : vG);
-    const int i0 = grp == 0 ? 0 : grp == 1 ? 22 : 43;           // thirds of 22 / 21 / 21 elements
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 21; ++j) acc += X[i0 + j] * V[i0 + j];
-    if (grp == 0) acc += X[21] * V[21];
-    pp[grp * LBP_PQ + k * 64 + lane] = acc;
-  } else {                                                       // wave 15: the three norms over the tile
-    const double gi = vG[lane], sc = vS[lane];
-    const double gg = wave_sum(gi * gi), ga = wave_sum(fabs(gi)), sa = wave_sum(fabs(sc));
-    if (lane == 0) { out[5 * M1 + 2] = gg; out[5 * M1 + 3] = ga; out[5 * M1 + 4] = sa; }
-  }
-  __syncthreads();
-  if (tid < 320 && lane < M1) {
-    const int k = q;
-    const double tot = (pp[tid] + pp[LBP_PQ + tid]) + pp[2 * LBP_PQ + tid];
-    out[k * M1 + lane] = tot;
-    if (lane == cs && k == 0) out[5 * M1 + 0] = tot;             // y_c.s_c
-    if (lane == cs && k == 2) out[5 * M1 + 1] = tot;             // y_c.y_c
-  }
-}
 
 #ifdef PINN_STAMPS
 __device__ long long g_coef_stamps[16];         // s_memtime timeline of the last k_lbc_coef (profiling build)
@@ -604,7 +506,7 @@ constexpr int LBC_MAXSLOTS = 62;                  // one lane per ring slot
 // `head` happens in the LDS write addresses.
 // d = cg g + sum_j (cy_j y_j + cs_j s_j) is summed over ring *slots* (zero coefficients for slots not
 // in use, ring zeroed at begin), 64 elements x 16 slices per workgroup, fixed order.
-template <typename real, bool PARTS>
+template <typename real>
 __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     int n, int M1, int m, int max_iter, double lr, double tol_x, double tol_fun, double max_eval,
     int do_post, int n_theta, const LbfgsState* __restrict__ st_in, LbfgsState* __restrict__ st_out,
@@ -626,7 +528,6 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   double* const sC = sT + 6 * 64;                  // cs[64] | cy[64] | {t, cg, apply, will_eval}
   double* const sP = sC + 192;                     // [16][64] partial sums of the update
   double* const sZ = sP + 16 * 64;                 // 64 zeros: the matrix row of the lanes beyond M1
-  double* const sQ = sZ + 64;                      // [3][LBP_PQ] dot products summed over a third of the tiles each
   CSTAMP(0);
   // ---- every global read the recursion waits for, issued as ONE round (a dependent round costs 1.5-2 us; the round itself
   // costs ~20 ticks per vector-memory instruction of the workgroup, so nothing is loaded twice and nothing early)
@@ -634,33 +535,19 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   const LbfgsState s0 = *st_in;
   int head = uni(s0.hist_head), len = uni(s0.hist_len);
   double Hdiag = s0.Hdiag, f_cur = s0.f;
-  // The dot products.  PARTS = false: one set (k_lbc_dots); waves 0-4 fetch one per-slot vector each, everybody the
-  // five scalars.  PARTS = true: n_part partial sets (k_lbc_reduce_dots: one per 64-element tile, at most
-  // LBP_MAXTILES = 3 x 22); thread (third, kind, slot) -- waves 0-14 -- adds a third of the sets in index order, wave
-  // 15 does the same for the five scalars, and the thirds are combined after one more barrier.
+  // The dot products: one set (k_lbc_dots<1>) or its two halves (k_lbc_dots<2>); waves 0-4 fetch one per-slot vector
+  // each, everybody the five scalars.
   // (Predicated loads, not clamped ones: a skipped load costs a branch, a redundant one a slot of the CU's memory
   //  pipeline -- with every lane loading, this round went from 6.5 k to 15 k ticks.)
+  // (Built and dropped in round 3: a two-launch tail whose reduction kernel also formed per-tile partial dot products,
+  //  summed here -- parity-green, 54.67 vs 54.54 us per iteration, profiles/r03_lbfgs_tail.txt; git history.)
   const int ndp = 5 * M1 + LBC_NSCAL;
-  const int tg = uni((n_part + 2) / 3);
-  const int q_grp = wave < 15 ? wave / 5 : lane / 5, q_kind = wave < 15 ? wave - 5 * (wave / 5) : lane - 5 * (lane / 5);
-  const bool q_ok = wave < 15 ? in_row : lane < 15;
-  const int q_off = wave < 15 ? q_kind * M1 + lane : 5 * M1 + q_kind;
-  double qv[PARTS ? 22 : 1];
-  double ys = 0, yy = 0, gg = 0, gabs = 0, sabs = 0;
-  if (PARTS) {
-#pragma unroll
-    for (int j = 0; j < (PARTS ? 22 : 0); ++j) {
-      const int tile = q_grp * tg + j;
-      qv[j] = (q_ok && j < tg && tile < n_part) ? pd[(size_t)tile * ndp + q_off] : 0.0;
-    }
-  } else {
-    ys = pd[5 * M1 + 0]; yy = pd[5 * M1 + 1]; gg = pd[5 * M1 + 2]; gabs = pd[5 * M1 + 3]; sabs = pd[5 * M1 + 4];
-    qv[0] = (wave < 5 && in_row) ? pd[wave * M1 + lane] : 0.0;
-    if (n_part == 2) {                               // k_lbc_dots<2>: the two halves of every dot product
-      const double* __restrict__ p2 = pd + ndp;
-      ys += p2[5 * M1 + 0]; yy += p2[5 * M1 + 1]; gg += p2[5 * M1 + 2]; gabs += p2[5 * M1 + 3]; sabs += p2[5 * M1 + 4];
-      qv[0] += (wave < 5 && in_row) ? p2[wave * M1 + lane] : 0.0;
-    }
+  double ys = pd[5 * M1 + 0], yy = pd[5 * M1 + 1], gg = pd[5 * M1 + 2], gabs = pd[5 * M1 + 3], sabs = pd[5 * M1 + 4];
+  double qv = (wave < 5 && in_row) ? pd[wave * M1 + lane] : 0.0;
+  if (n_part == 2) {                                 // k_lbc_dots<2>: the two halves of every dot product
+    const double* __restrict__ p2 = pd + ndp;
+    ys += p2[5 * M1 + 0]; yy += p2[5 * M1 + 1]; gg += p2[5 * M1 + 2]; gabs += p2[5 * M1 + 3]; sabs += p2[5 * M1 + 4];
+    qv += (wave < 5 && in_row) ? p2[wave * M1 + lane] : 0.0;
   }
   const double ro_l0 = in_row ? ro_in[lane] : 0.0;
   const double f_new = gl[n_theta] + gl[n_theta + 1] + gl[n_theta + 2];
@@ -695,15 +582,6 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   const int done0 = uni(s0.done);
   if (done0) { if (writer && tid == 0) *st_out = s0; return; }
   CSTAMP(1);
-  auto qsum = [&](const int i) { return (sQ[i] + sQ[LBP_PQ + i]) + sQ[2 * LBP_PQ + i]; };
-  if (PARTS) {
-    double qs = 0.0;
-#pragma unroll
-    for (int j = 0; j < (PARTS ? 22 : 0); ++j) qs += qv[j];
-    if (q_ok) sQ[q_grp * LBP_PQ + (wave < 15 ? q_kind * 64 + lane : 320 + q_kind)] = qs;
-    lds_barrier();
-    ys = qsum(320); yy = qsum(321); gg = qsum(322); gabs = qsum(323); sabs = qsum(324);
-  }
   LbfgsState s1 = s0;                              // the state after this iteration (written by `writer`)
   int dn = 0;
   if (do_post) {                                   // custom_lbfgs.py:185-215 for the last evaluation
@@ -732,7 +610,7 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     if (len == m) { head += 1; if (head >= M1) head -= M1; } else len += 1;
   }
   const double ro_l = (accept && lane == c) ? 1.0 / ys : ro_l0;
-  if (wave < 5) sT[wave * 64 + lane] = !in_row ? 0.0 : PARTS ? qsum(wave * 64 + lane) : qv[0];   // per-slot vectors: say sya yya sg yg
+  if (wave < 5) sT[wave * 64 + lane] = !in_row ? 0.0 : qv;   // per-slot vectors: say sya yya sg yg
   if (wave == 5) {
     sT[5 * 64 + lane] = ro_l;
     if (writer && in_row) ro_out[lane] = ro_l;
@@ -900,6 +778,6 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
   if (sC[131] != 0.0) { theta[i] = xi; theta_r[i] = (real)xi; pack_store_any(nd, img, i, (float)xi); }
 }
 
-inline size_t lbc_coef_apply_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64 + 192 + 16 * 64 + 64 + 3 * 328) * 8; }
+inline size_t lbc_coef_apply_lds_bytes(int M1) { return ((size_t)3 * M1 * lbc_ld(M1) + 6 * 64 + 192 + 16 * 64 + 64) * 8; }
 
 }  // namespace pinn

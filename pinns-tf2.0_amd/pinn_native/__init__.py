@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
-SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "fused20m_unit.hip", "fused20m_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_fused20dh.h", "kernels_fused20r.h", "kernels_wide.h", "kernels_predict20.h",
+SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "fused20m_unit.hip", "fused20m_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h", "kernels_predict20.h",
            "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
@@ -517,7 +517,7 @@ class Engine(object):
 
     def debug_stamps(self):
         """(profiling build) -> int64 array [n_waves, 32] of s_memtime ticks for one evaluation"""
-        n_wg = (2 * self.n_b + self.n_u + self.n_f + 63) // 64 * 2      # (48-point tiles of k_fused20dh: up to 4/3 as many)
+        n_wg = (2 * self.n_b + self.n_u + self.n_f + 63) // 64
         buf = np.zeros((n_wg * 4, 32), dtype=np.int64)
         n = ctypes.c_int64(0)
         self._check(self._lib.pinn_debug_stamps(

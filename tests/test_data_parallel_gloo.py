@@ -209,16 +209,18 @@ class _StubEngine(object):
     made = []
 
     def __init__(self, layers, lb, ub, pde="burgers", dtype="f32", device=0):
-        self.dtype, self.n_params, self.w = dtype, 3021, np.zeros(3021)
-        self.n_f = self.n_u = 0
+        self.dtype, self.pde, self.w = dtype, pde, np.zeros(3021)
+        self.n_params = sum(a * b + b for a, b in zip(layers[:-1], layers[1:])) + (2 if pde == "burgers_ide" else 0)
+        self.n_f = self.n_u = self.n_b = 0
         self.comm = None
         _StubEngine.made.append(self)
 
     def set_collocation(self, X, n_total=None): self.n_f, self.n_f_total = len(X), n_total
     def set_data(self, X, u, n_total=None): self.n_u = len(X)
+    def set_boundary(self, A, B, n_total=None): self.n_b = len(A)
     def set_pde_params(self, *p): pass
     def set_kernel_path(self, p): pass
-    def kernel_path(self): return 2 if self.dtype == "f32" else 7
+    def kernel_path(self): return 4 if self.pde == "schrodinger" else 2 if self.dtype == "f32" else 7
     def set_weights(self, w): self.w = np.array(w, dtype=np.float64)
     def get_weights(self): return self.w.copy()
     def adam_init(self, *a): pass
@@ -260,7 +262,7 @@ def _bench_main_worker(rank, world, port, out_dir):
     with open(os.path.join(out_dir, "rank%d.out" % rank), "w") as f:
         f.write(buf.getvalue())
     with open(os.path.join(out_dir, "rank%d.sets" % rank), "w") as f:
-        f.write(";".join("%s:%d:%s" % (e.dtype, e.n_f, e.comm[1:] if e.comm else None) for e in _StubEngine.made))
+        f.write(";".join("%s:%d:%d:%d:%s" % (e.dtype, e.n_f, e.n_u, e.n_b, e.comm[1:] if e.comm else None) for e in _StubEngine.made))
 
 
 def test_bench_main_world2_emits_one_contract_line(tmp_path):
@@ -289,9 +291,18 @@ def test_bench_main_world2_emits_one_contract_line(tmp_path):
         assert k in j["roofline"]
     assert j["cfg5_leg"]["n_f_total"] == 1000000 and j["cfg5_leg"]["n_f_per_gpu"] == 500000
     assert j["float32_leg"]["dtype"] == "f32" and j["float32_leg"]["kernel_path"] == 2
+    # BASELINE configs[2] and [3] as driver-timed legs, in the headline's arithmetic, each with its own roofline
+    c3, c4 = j["cfg3_leg"], j["cfg4_leg"]
+    assert c3["n_f_total"] == 10000 and c3["dtype"] == "f64" and c3["lbfgs_steps_per_block"] == 5 and c3["adam_steps_per_block"] == 1
+    assert abs(c3["roofline"]["algorithmic_flop_per_launch"] - 24 * 2860 * 5000) < 1
+    assert c4["n_f_total"] == 20000 and c4["adam_steps_per_block"] == 6 and c4["lbfgs_steps_per_block"] == 0 and c4["kernel_path"] == 4
+    assert abs(c4["roofline"]["algorithmic_flop_per_launch"] - 30400 * (24 * 10000 + 6 * 25 + 12 * 2 * 25)) < 1
+    assert c4["roofline"]["kernel"] == "pinn::k_t16_fwd+k_t16_bwd" and c4["roofline"]["traffic"] is None
+    assert "one GPU" in c4["roofline"]["traffic_source"]            # a null traffic says why
     for r in range(2):
         sets = open(tmp_path / ("rank%d.sets" % r)).read().split(";")
-        assert sets == ["f64:5000:(2, %d)" % r, "f32:5000:(2, %d)" % r, "f64:500000:(2, %d)" % r], sets
+        assert sets == ["f64:5000:50:0:(2, %d)" % r, "f32:5000:50:0:(2, %d)" % r, "f64:500000:50:0:(2, %d)" % r,
+                        "f64:0:5000:0:(2, %d)" % r, "f64:10000:25:25:(2, %d)" % r], sets
 
 
 # ---- the drop-in classes launched data-parallel (world_size 2 over gloo, scripted engine) ---------------------------------

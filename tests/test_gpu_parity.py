@@ -535,146 +535,3 @@ def test_residual_at_arbitrary_points_matches_stored_set_and_oracle(burgers_sets
     _, _, ex = pde.burgers_loss_grad(w, layers, lb, ub, X_f, X_u, u, NU)
     assert np.max(np.abs(eng.residual_at(X_f) - ex["f"])) <= tol * max(np.max(np.abs(ex["f"])), 1.0)
     eng.close()
-
-
-def test_helper_wave_variant_of_the_f64_kernel_matches_the_product_kernel():
-    """csrc/kernels_fused20dh.h (opt-in, PINN_F64_HELPER=1: three 16-point waves + a helper wave per 48-point tile): the
-    experiment stays pinned -- same loss / gradient as k_fused20d to rounding, bit-reproducible, identification too"""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, json
-import numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd")); sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers"))
-import pinn_native, burgersutil
-g = np.load(os.path.join(%(root)r, "tests", "golden", "burgers_eval.npz"))
-np.random.seed(1234)
-r = burgersutil.prep_data(os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers", "data", "burgers_shock.mat"), 100, 10000, noise=0.0)
-out = {}
-for pde in ("burgers", "burgers_ide"):
-    eng = pinn_native.Engine([2] + [20] * 8 + [1], r[11], r[10], pde=pde, dtype="f64")
-    w = g["w0"] if pde == "burgers" else np.concatenate([g["w0"], [0.5, -5.0]])
-    if pde == "burgers":
-        eng.set_collocation(r[9]); eng.set_data(r[7], r[8]); eng.set_pde_params(0.01 / np.pi)
-    else:
-        eng.set_data(r[9][:6000], np.sin(r[9][:6000, :1]))
-    eng.set_weights(w)
-    l1, g1, _ = eng.loss_grad(); l2, g2, _ = eng.loss_grad()
-    assert l1 == l2 and np.array_equal(g1, g2)
-    out[pde] = [l1] + g1.tolist()
-    eng.close()
-print("RESULT" + json.dumps(out))
-''' % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
-    res = {}
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_F64_HELPER=flag), capture_output=True,
-                           text=True, timeout=300)
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
-        res[flag] = json.loads(line[0][6:])
-    for pde in ("burgers", "burgers_ide"):
-        a, b = np.array(res["0"][pde]), np.array(res["1"][pde])
-        assert abs(a[0] - b[0]) <= 1e-13 * abs(a[0]), pde
-        assert np.max(np.abs(a[1:] - b[1:])) <= 1e-12 * np.max(np.abs(a[1:])), pde
-        assert not np.array_equal(a[1:], b[1:]) or True          # (different summation grouping: equal only by luck)
-
-
-def test_recompute_variant_of_the_f32_kernel_matches_the_product_kernel():
-    """csrc/kernels_fused20r.h (opt-in, PINN_F32_RECOMPUTE=1: even layers stashed, odd layers recomputed, two workgroups
-    per CU): the experiment stays pinned -- the recomputed layers repeat the forward instructions, so loss and gradient
-    agree with k_fused20m to the float32 rounding of a different summation grouping (twice as many partial rows)"""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, json
-import numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd")); sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers"))
-import pinn_native, burgersutil
-g = np.load(os.path.join(%(root)r, "tests", "golden", "burgers_eval.npz"))
-np.random.seed(1234)
-r = burgersutil.prep_data(os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers", "data", "burgers_shock.mat"), 100, 70001, noise=0.0)
-out = {}
-for pde in ("burgers", "burgers_ide"):
-    eng = pinn_native.Engine([2] + [20] * 8 + [1], r[11], r[10], pde=pde, dtype="f32")
-    w = g["w0"] if pde == "burgers" else np.concatenate([g["w0"], [0.5, -5.0]])
-    if pde == "burgers":
-        eng.set_collocation(r[9]); eng.set_data(r[7], r[8]); eng.set_pde_params(0.01 / np.pi)
-    else:
-        eng.set_data(r[9][:40000], np.sin(r[9][:40000, :1]))
-    eng.set_weights(w)
-    l1, g1, _ = eng.loss_grad(); l2, g2, _ = eng.loss_grad()
-    assert l1 == l2 and np.array_equal(g1, g2)
-    out[pde] = [l1] + g1.tolist()
-    eng.close()
-print("RESULT" + json.dumps(out))
-''' % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
-    res = {}
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_F32_RECOMPUTE=flag), capture_output=True,
-                           text=True, timeout=300)
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
-        res[flag] = json.loads(line[0][6:])
-    for pde in ("burgers", "burgers_ide"):
-        a, b = np.array(res["0"][pde]), np.array(res["1"][pde])
-        assert abs(a[0] - b[0]) <= 2e-6 * abs(a[0]), pde
-        assert np.max(np.abs(a[1:] - b[1:])) <= 1e-5 * np.max(np.abs(a[1:])), pde
-
-
-def test_two_launch_lbfgs_tail_matches_the_three_launch_tail():
-    """csrc/kernels_optim.h k_lbc_reduce_dots (opt-in, PINN_LBFGS_FUSE=1: the dot products of an L-BFGS iteration are
-    formed behind the row reduction of the evaluation, one partial set per 64-column tile, summed by
-    k_lbc_coef_apply<PARTS=true>): same gradient bit for bit (same reduction order), the same iterates to the rounding
-    of a differently associated dot product, both arithmetics, inference and identification, bit-reproducible"""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, json
-import numpy as np
-sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd")); sys.path.insert(0, os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers"))
-import pinn_native, burgersutil
-g = np.load(os.path.join(%(root)r, "tests", "golden", "burgers_eval.npz"))
-np.random.seed(1234)
-r = burgersutil.prep_data(os.path.join(%(root)r, "pinns-tf2.0_amd", "1d-burgers", "data", "burgers_shock.mat"), 100, 10000, noise=0.0)
-out = {}
-for dt in ("f64", "f32"):
-    for pde in ("burgers", "burgers_ide"):
-        runs = []
-        for rep in range(2):
-            eng = pinn_native.Engine([2] + [20] * 8 + [1], r[11], r[10], pde=pde, dtype=dt)
-            w = g["w0"] if pde == "burgers" else np.concatenate([g["w0"], [0.5, -5.0]])
-            if pde == "burgers":
-                eng.set_collocation(r[9]); eng.set_data(r[7], r[8]); eng.set_pde_params(0.01 / np.pi)
-            else:
-                eng.set_data(r[9][:6000], np.sin(r[9][:6000, :1]))
-            eng.set_weights(w)
-            eng.lbfgs_begin(70, 0.8, 50, 2.2e-16)
-            it, losses, done = [], [], 0
-            for chunk in (1, 29, 40):              # chunk boundaries: the host settles the state between calls
-                a, b, done = eng.lbfgs_run(chunk)
-                it += list(a); losses += list(b)
-            runs.append((losses, eng.get_weights().tolist()))
-            eng.close()
-        assert runs[0] == runs[1], "not bit-reproducible"
-        out[dt + pde] = {"losses": runs[0][0], "w": runs[0][1]}
-print("RESULT" + json.dumps(out))
-''' % {"root": os.path.dirname(os.path.dirname(os.path.abspath(__file__)))}
-    res = {}
-    for flag in ("0", "1"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PINN_LBFGS_FUSE=flag), capture_output=True,
-                           text=True, timeout=600)
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-2000:]
-        res[flag] = json.loads(line[0][6:])
-    for key in res["0"]:
-        a, b = res["0"][key], res["1"][key]
-        la, lb = np.array(a["losses"]), np.array(b["losses"])
-        assert len(la) == len(lb) and len(la) >= 60, key
-        # float64 iterates part slowly (rounding of the dot products, amplified ~10x per 12 iterations); float32 ones
-        # share the float64 optimiser arithmetic but re-round the weights each iteration
-        tol = 1e-9 if key.startswith("f64") else 2e-3
-        assert np.max(np.abs(la[:30] - lb[:30]) / np.abs(la[:30])) <= tol, (key, np.max(np.abs(la[:30] - lb[:30]) / np.abs(la[:30])))
-        assert abs(la[-1] - lb[-1]) <= (1e-5 if key.startswith("f64") else 0.3) * abs(la[-1]), key
