@@ -27,6 +27,7 @@
 #include "kernels_disc.h"
 #include "kernels_sampling.h"
 #include "kernels_tile16.h"
+#include "kernels_tile16f.h"
 #include "kernels_xgmi.h"
 #include "kernels_predict20.h"
 
@@ -242,8 +243,12 @@ static bool wide_ok(const pinn_ctx* c) {
 
 // the shape-generic MFMA sweeps (kernels_tile16.h): any width up to 128 (64 in float64), any depth
 static bool tile16_ok(const pinn_ctx* c) { return !is_disc(c) && c->nd.width <= 128 && c->nd.n_out <= 2; }
+// the fused float64 sweep (kernels_tile16f.h): forward + reverse of a group in one kernel, stash in registers
+static bool t16_fused_ok(const pinn_ctx* c) {
+  return tile16_ok(c) && c->dtype == PINN_F64 && c->nd.width > 64 && c->nd.n_hidden == 4;
+}
 static bool t16_fwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 5; }
-static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6; }
+static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6 || c->path == 8; }   // (one partial row per workgroup, t16_wgs)
 // Launch plan of the shape-generic sweeps for a chunk of `pts` points (measured, profiles/r01_t16_plan.txt):
 //   widths <= 64, float32: few groups (<= 3 per CU: every group resident at once) -> weights straight from L2, three
 //     workgroups per CU; many groups -> weights staged in LDS, two workgroups per CU;
@@ -545,6 +550,29 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       const int pts = (sd.n_pad - base < c->chunk) ? sd.n_pad - base : c->chunk;
       const dim3 grid(pts / 64), block(64);
       bool fwd_done = false;
+      if constexpr (sizeof(real) == 8) {
+        if (c->path == 8) {
+          // periodic-boundary seeds read the outputs of a partner point another workgroup may own: the outputs of the
+          // boundary groups (the first 2 n_b points of the set) are produced by a forward sweep of their own first
+          if (PDE == 2 && base == 0 && sd.n_b > 0) {
+            const int bpts = (2 * sd.n_b + 15) / 16 * 16;
+            if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, 0, bpts < pts ? bpts : pts, lbx, lbt, sx, st)) return rc;
+          }
+          static unsigned long long attr = 0;
+          if (first_call_on_device(attr))
+            HIPCHK(hipFuncSetAttribute((const void*)k_t16_fused<PDE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)t16_fused_lds()));
+          if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
+          const int rows_cap = t16_wgs(c, c->chunk);
+          const int wgs = t16_wgs(c, pts) < rows_cap ? t16_wgs(c, pts) : rows_cap;
+          hipLaunchKernelGGL((k_t16_fused<PDE, 4>), dim3(wgs), dim3(512), t16_fused_lds(), c->stream, c->nd, sd,
+                             (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, (const double*)c->tgt,
+                             base, sd.n_pad, pts / 16, (double)lbx, (double)lbt, (double)sx, (double)st, (double)c->nu,
+                             (vec4<double>*)c->O, (double*)c->part, c->R, ci > 0 ? 1 : 0);
+          HIPCHK(hipGetLastError());
+          continue;
+        }
+      }
       if (t16_fwd_on(c)) {
         if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, base, pts, lbx, lbt, sx, st)) return rc;
         fwd_done = true;
@@ -1071,7 +1099,7 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   }
   // default kernel family: 2 width-20 f32 (MFMA GEMVs, register stash), 7 its float64 counterpart (4x4x4 MFMA GEMVs,
   // no exchange), 1 width-20 HBM-stash, 3 wide MFMA sweeps (width 100, 2 outputs), 4 shape-generic MFMA sweeps, 0 generic
-  c->path = fused_regs_ok(c) ? 2 : fused_f64_ok(c) ? 7 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : tile16_ok(c) ? 4 : 0;
+  c->path = fused_regs_ok(c) ? 2 : fused_f64_ok(c) ? 7 : fused_ok(c) ? 1 : wide_ok(c) ? 3 : t16_fused_ok(c) ? 8 : tile16_ok(c) ? 4 : 0;
   *out = c;
   return 0;
 }
@@ -1785,9 +1813,10 @@ int pinn_sync(pinn_ctx* c) {
 }
 
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
-  REQUIRE(c && path >= 0 && path <= 7, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
+  REQUIRE(c && path >= 0 && path <= 8, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
           "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half), "
-          "7 (fused width-20 float64, register stash)");
+          "7 (fused width-20 float64, register stash), 8 (fused float64 MFMA sweep, widths 65..128, 4 hidden layers)");
+  if (path == 8) REQUIRE(t16_fused_ok(c), "the fused float64 sweep needs float64, hidden width 65..128 and 4 hidden layers");
   if (path >= 4 && path <= 6) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
   if (path == 7)
     REQUIRE(fused_f64_ok(c), "the float64 register-stash path needs float64, hidden width 20, 4, 6 or 8 hidden layers and a Burgers problem");

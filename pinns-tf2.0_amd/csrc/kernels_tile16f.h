@@ -1,0 +1,364 @@
+// kernels_tile16f.h -- k_t16_fused: the float64 MFMA sweeps of kernels_tile16.h for hidden widths 65..128 with the
+// forward and the reverse sweep of a 16-point group in ONE kernel and the stash in registers -- no HBM stash.
+//
+// Why (BASELINE configs[3]: the Schrodinger net 2-100x4-2 in the reference's arithmetic, N_f = 20000).  The two-kernel
+// sweeps move 1.25 GB per evaluation for 0.3 MB of coordinates (profiles/r04_pmc_fetch_write_cfg4.txt): k_t16_fwd writes
+// the 6.4 KB/point stash (253 MB), k_t16_bwd reads it back and read-modify-writes the 246 KB gradient row of its
+// workgroup once per group (295 MB raw fetched, 366 MB written); ablation (profiles/r03_ablate_t16_f64_w8.txt): stash
+// stores / loads -16 / -64 us, row read-modify-write -83 us of 583.
+//
+// What fits on the chip (one CU, float64, width 100 padded to 7 x 16 = 112 rows, 16-point group):
+//   register file 512 KB, LDS 160 KB.
+//   exchange tiles  2 x [128][17] x 32 B                           = 139 KB   LDS (B operands of the layer GEMMs, both
+//                                                                             operands of the weight-gradient tiles)
+//   stash (a, z_x, z_t, z_xx), hidden layers 1..H-1: 3 x 51.2 KB   = 154 KB   -> 96 registers per lane at 8 waves
+//   weight-gradient accumulators 3 x 49 tiles x 256 x 8 B          = 301 KB   -> 147 registers per lane at 8 waves
+//   the sweeps' own working set (k_t16_bwd: 175 - 32 stash reads)  ~ 143 registers per lane
+// 96 + 147 + 143 = 386 > 256 registers per lane (two waves per SIMD; one wave per SIMD has 512 but was measured 30 %
+// slower on these sweeps, profiles/r03_t16_ab.txt), and LDS has 21 KB left.  So ONE of the two traffic sources can go.
+// This kernel removes the stash (both directions: 509 MB, and one launch); the gradient rows stay a read-modify-write.
+// Layer 0's stash entry is tanh of an affine function of (x, t): recomputed where it is needed, never stored.
+//
+// Structure: exactly the arithmetic of k_t16_fwd<double, 8, false, 8> followed by k_t16_bwd<double, 8, PDE, false, 8>
+// (same matrix-instruction order, same tanh, same summation orders -- results are bit-identical to the two-kernel
+// path), with every stash access turned into a register access of the lane that produced the entry: wave w owns
+// feature tile w (rows 16 w + out_row(lane, r)) in the forward GEMM AND in the adjoint GEMM, so an entry is produced
+// and consumed by the same lane; the elementwise passes of k_t16_bwd that read the stash in (row, point) order are
+// re-dealt to the owning lanes.  After the forward sweep the two exchange tiles already hold what the first reverse
+// step needs (outputs of layers H-1 and H-2).
+// Periodic-boundary seeds (1dcomplex-schrodinger/inf_cont_schrodinger.py:107-129) read the OUTPUTS of a partner point
+// that another workgroup may own: the engine runs k_t16_fwd over the boundary groups first (a handful of groups).
+#pragma once
+#include <type_traits>
+#include "kernels_tile16.h"
+
+namespace pinn {
+
+inline size_t t16_fused_lds() {
+  return (size_t)(2 * T16Geo<8>::TILE * 4 + 2 * 8 * 2 * 16 * 4 + 2 * 16 * 4 + 32 + 7 * 16) * sizeof(double);
+}
+
+template <int PDE, int H>
+__global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const double* __restrict__ th,
+                                                   const double* __restrict__ xs, const double* __restrict__ ts,
+                                                   const double* __restrict__ tgt, int base, int n_pad, int n_groups,
+                                                   double lbx, double lbt, double sx, double st, double nu,
+                                                   vec4<double>* __restrict__ O, double* __restrict__ part, int R,
+                                                   int accumulate) {
+  using real = double;
+  using TR = FusedTraits<double>;
+  using acc_t = typename TR::acc_t;
+  using GEO = T16Geo<8>;
+  using V4 = vec4<double>;
+  static_assert(H >= 2, "at least one hidden-to-hidden layer");
+  constexpr int NT = 8, NWV = 8, WP = GEO::WP, PD = GEO::PD, RP = 4 * NWV, THREADS = 64 * NWV;
+  constexpr int NI = WP / RP, KS = 2 * NWV, NKO = WP / KS, DEPTH = T16_DEPTH;
+  (void)NT;
+  extern __shared__ __attribute__((aligned(16))) char t16_smem[];
+  V4* const T0 = reinterpret_cast<V4*>(t16_smem);
+  V4* const T1 = T0 + GEO::TILE;
+  real* const red = reinterpret_cast<real*>(T1 + GEO::TILE);     // [2 NWV][2][16][4] output-layer partials
+  V4* const seeds = reinterpret_cast<V4*>(red + 2 * NWV * 2 * 16 * 4);   // [2][16]
+  real* const hxy = reinterpret_cast<real*>(seeds + 32);          // [2][16] normalised inputs
+  real* const lsum = hxy + 32;                                    // [7][16] per-point-slot sums over the groups: loss parts (3),
+                                                                  // lambda gradients (2), output-bias gradients (2)
+  const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int W = nd.width, NO = nd.n_out;
+  const int ksteps = (W + 3) / 4, nchunks = (ksteps + 3) >> 2;
+  const bool tile_live = 16 * wave < W;                           // wave-uniform: this wave's feature tile has real rows
+  real* __restrict__ row = part + (size_t)blockIdx.x * R;
+  real c1 = real(1), c2 = nu;
+  if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp_r(th[nd.n_net + 1]); }
+
+  if (!accumulate) {
+    for (int i = tid0; i < R; i += THREADS) row[i] = real(0);
+    __syncthreads();                          // (global stores of one workgroup, read back by the same workgroup)
+  }
+  if (tid0 < 7 * 16) lsum[tid0] = real(0);    // (published by the first barrier of the group loop)
+
+  // (k_t16_fwd keeps dense 0's parameters and the output layer's k-slice in registers across groups: 40 registers
+  //  this kernel needs for the stash -- they are re-read from L2 per group instead)
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int lp0 = grp * 16;
+    // The lane index is re-read through an opaque asm once per group: every per-lane address of the body (six layer
+    // matrices, the gradient-row entries of 49 tiles, biases, tiles) is loop-invariant, and with the layer loops
+    // unrolled hipcc hoisted ~60 64-bit addresses out of the group loop and spilled them (568 B of scratch per lane)
+    int lane = tid0 & 63;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane, m = lane & 15, g = lane >> 4, pe = lane & 15;
+  // layer 0's stash entry of (feature j, point with normalised inputs hx, ht): recomputed, never stored
+  auto dense0 = [&](const int j, const real hx, const real ht) {
+    const real w0 = th[nd.off_w[0] + j], w1 = th[nd.off_w[0] + W + j], b0 = th[nd.off_b[0] + j];
+    return V4{tanh_mm(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
+  };
+  // one layer GEMM of this wave's feature tile: acc_c[r] = sum_k A(row, k) B_c[k][point m], weights straight from L2
+  // with DEPTH chunks of four k-steps in flight (k_t16_fwd / k_t16_bwd, WLDS == false).  TRANSPOSED: A(row, k) =
+  // Wm[row * W + k] (adjoint GEMM), else Wm[k * W + row] (forward GEMM)
+  auto gemm = [&](const real* __restrict__ Wm, const V4* __restrict__ Bt, auto tr_tag, acc_t& a0, acc_t& a1,
+                  acc_t& a2, acc_t& a3) {
+    constexpr bool transposed = decltype(tr_tag)::value;
+    const int ra = 16 * wave + m;
+    real wq[DEPTH + 1][4];
+    auto fetch = [&](int c, real (&dst)[4]) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * (4 * c + u) + g;
+        dst[u] = (k < W && ra < W) ? (transposed ? Wm[ra * W + k] : Wm[k * W + ra]) : real(0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) fetch(q, wq[q]);
+    for (int c = 0; c < nchunks; ++c) {
+      fetch(c + DEPTH, wq[DEPTH]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (4 * c + u >= ksteps) break;                           // last chunk: only the k-steps that exist (uniform)
+        const V4 b = Bt[(4 * (4 * c + u) + g) * PD + m];
+        a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
+        a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
+        a2 = t16_mfma<real, acc_t>(wq[0][u], b.z, a2);
+        a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
+      }
+#pragma unroll
+      for (int q = 0; q < DEPTH; ++q) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
+      }
+    }
+  };
+
+    // =========================================================================================== forward sweep
+    {  // dense 0: items (feature j, point pe), point fastest
+      const real x = xs[base + lp0 + pe], t = ts[base + lp0 + pe];
+      const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
+      if (tid < 16) { hxy[tid] = hx; hxy[16 + tid] = ht; }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int j = (tid >> 4) + RP * i;
+        V4 c{0, 0, 0, 0};
+        if (j < W) {
+          real d1, d2;
+          c = channels_of(dense0(j, hx, ht), d1, d2);
+        }
+        T0[j * PD + pe] = c;
+      }
+    }
+    V4 stash[H - 1][4];                       // hidden layers 1..H-1, this lane's four rows of its wave's tile
+    V4* Tin = T0;
+    V4* Tout = T1;
+#pragma unroll
+    for (int l = 1; l < H; ++l) {
+      __syncthreads();                        // Tin published
+      if (!tile_live) {                       // tile entirely in the padding: zeros
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Tout[(16 * wave + TR::out_row(lane, r)) * PD + m] = V4{0, 0, 0, 0};
+          stash[l - 1][r] = V4{0, 0, 0, 0};
+        }
+      } else {
+        const real* __restrict__ bl = th + nd.off_b[l];
+        real bj[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * wave + TR::out_row(lane, r);
+          bj[r] = j < W ? bl[j] : real(0);
+        }
+        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+        gemm(th + nd.off_w[l], Tin, std::false_type{}, a0, a1, a2, a3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * wave + TR::out_row(lane, r);           // feature; the point is m
+          V4 c{0, 0, 0, 0}, s{0, 0, 0, 0};
+          if (j < W) {
+            s = V4{tanh_mm(a0[r] + bj[r]), a1[r], a2[r], a3[r]};
+            real d1, d2;
+            c = channels_of(s, d1, d2);
+          }
+          stash[l - 1][r] = s;
+          Tout[j * PD + m] = c;
+        }
+      }
+      V4* tmp = Tin; Tin = Tout; Tout = tmp;
+    }
+    __syncthreads();
+    {  // linear output layer: thread = (k-slice ks8, output o, point pe); the slices are summed through LDS
+      const int o = (tid >> 4) & 1, ks8 = tid >> 5;
+      V4 acc{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < NKO; ++i) {
+        const int k = ks8 + KS * i;
+        const V4 b = Tin[k * PD + pe];
+        const real w = (k < W && o < NO) ? th[nd.off_w[H] + k * NO + o] : real(0);
+        acc.x += b.x * w; acc.y += b.y * w; acc.z += b.z * w; acc.w += b.w * w;
+      }
+      reinterpret_cast<V4*>(red)[(ks8 * 2 + o) * 16 + pe] = acc;
+      __syncthreads();
+      if (ks8 == 0 && o < NO) {
+        V4 tot = reinterpret_cast<V4*>(red)[(0 * 2 + o) * 16 + pe];
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+          const V4 v = reinterpret_cast<V4*>(red)[(q * 2 + o) * 16 + pe];
+          tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+        }
+        tot.x += th[nd.off_b[H] + o];
+        O[(size_t)o * n_pad + base + lp0 + pe] = tot;
+      }
+    }
+    __syncthreads();                          // the group's outputs are in memory (written and read by this workgroup)
+    // =========================================================================================== reverse sweep
+    if (tid < 16) {
+      const int pt = base + lp0 + tid;
+      V4 sb[2];
+      real lt[3], dl[2];
+      point_seeds<real, PDE>(sd, pt, n_pad, O, tgt, c1, c2, sb, lt, dl);
+      seeds[tid] = sb[0]; seeds[16 + tid] = sb[1];
+      lsum[tid] += lt[0]; lsum[16 + tid] += lt[1]; lsum[32 + tid] += lt[2];
+      lsum[48 + tid] += dl[0]; lsum[64 + tid] += dl[1];
+      lsum[80 + tid] += sb[0].x; lsum[96 + tid] += sb[1].x;
+    }
+    __syncthreads();
+    // Tin = outputs of layer H-1 (inputs of dense H), Tout = outputs of layer H-2 (inputs of layer H-1): the reverse
+    // sweep starts with TI = Tout (A operand of dW_{H-1}) and overwrites Tin with the adjoint of layer H-1's
+    // pre-activations
+    V4* TI = Tout;
+    V4* Bcur = Tin;
+    {  // dense H (linear): z_bar = seeds.  This lane's four rows j of tile `wave`, point m: adjoint of layer H-1's
+       // pre-activations, gradient of the output weights (sum over the 16 points = the 16 lanes of a DPP row)
+      const V4 s0 = seeds[m], s1 = seeds[16 + m];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * wave + TR::out_row(lane, r);
+        V4 zb{0, 0, 0, 0};
+        real gw0 = 0, gw1 = 0;
+        if (j < W) {
+          const V4 s = stash[H - 2][r];
+          real d1, d2;
+          const V4 in = channels_of(s, d1, d2);
+          const real w0 = th[nd.off_w[H] + j * NO], w1 = NO > 1 ? th[nd.off_w[H] + j * NO + 1] : real(0);
+          V4 ob{s0.x * w0 + s1.x * w1, s0.y * w0 + s1.y * w1, s0.z * w0 + s1.z * w1, s0.w * w0 + s1.w * w1};
+          zb = preact_adjoint(s, ob);
+          gw0 = dot4(in, s0);
+          gw1 = dot4(in, s1);
+        }
+        gw0 = sum16(gw0);
+        gw1 = sum16(gw1);
+        if (m == 0 && j < W) {
+          row[nd.off_w[H] + j * NO] += gw0;
+          if (NO > 1) row[nd.off_w[H] + j * NO + 1] += gw1;
+        }
+        Bcur[j * PD + m] = zb;
+      }
+    }
+#pragma unroll
+    for (int d = H - 1; d >= 1; --d) {
+      __syncthreads();                        // Bcur (z_bar of layer d), TI (inputs of layer d) published
+      // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j
+      const int ntl = (W + 15) >> 4;                              // live tiles per side: the others are padding
+      for (int tau = wave; tau < ntl * ntl; tau += NWV) {
+        const int rt = tau / ntl, ct = tau - rt * ntl;
+        const int j = 16 * ct + m;
+        real old[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rt + TR::out_row(lane, r);
+          // the first group of a fresh row adds to the zeros this workgroup has just written: nothing to fetch
+          old[r] = (k < W && j < W && !(T16_SKIP_FIRST && !accumulate && grp == (int)blockIdx.x))
+                       ? row[nd.off_w[d] + k * W + j] : real(0);
+        }
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
+          acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
+          acc = t16_mfma<real, acc_t>(A.y, B.y, acc);
+          acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
+          acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rt + TR::out_row(lane, r);
+          if (k < W && j < W) row[nd.off_w[d] + k * W + j] = old[r] + acc[r];
+        }
+      }
+      if (tid < W) {                          // bias gradient of layer d
+        real sb_ = 0;
+        for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
+        row[nd.off_b[d] + tid] += sb_;
+      }
+      __syncthreads();                        // every wave is done reading TI (dW): it becomes the output tile
+      // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
+      V4* const Bnxt = TI;
+      if (!tile_live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bnxt[(16 * wave + TR::out_row(lane, r)) * PD + m] = V4{0, 0, 0, 0};
+      } else {
+        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+        gemm(th + nd.off_w[d], Bcur, std::true_type{}, a0, a1, a2, a3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * wave + TR::out_row(lane, r);
+          V4 v{0, 0, 0, 0};
+          if (k < W) {
+            const V4 sk = d >= 2 ? stash[d >= 2 ? d - 2 : 0][r] : dense0(k, hxy[m], hxy[16 + m]);
+            v = preact_adjoint(sk, V4{a0[r], a1[r], a2[r], a3[r]});
+          }
+          Bnxt[k * PD + m] = v;
+        }
+      }
+      __syncthreads();                        // every wave is done reading Bcur (adjoint GEMM): it is refilled
+      if (d >= 2) {                           // inputs of layer d-1 = output channels of layer d-2
+        if (d >= 3) {                         // ... from the owning lanes' registers
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * wave + TR::out_row(lane, r);
+            V4 c{0, 0, 0, 0};
+            if (j < W) { real d1, d2; c = channels_of(stash[d >= 3 ? d - 3 : 0][r], d1, d2); }
+            Bcur[j * PD + m] = c;
+          }
+        } else {                              // ... layer 0: recomputed, items (feature j, point pe)
+          const real hx = hxy[pe], ht = hxy[16 + pe];
+#pragma unroll
+          for (int i = 0; i < NI; ++i) {
+            const int j = (tid >> 4) + RP * i;
+            V4 c{0, 0, 0, 0};
+            if (j < W) {
+              real d1, d2;
+              c = channels_of(dense0(j, hx, ht), d1, d2);
+            }
+            Bcur[j * PD + pe] = c;
+          }
+        }
+      }
+      V4* tmp = Bcur; Bcur = TI; TI = tmp;     // roles swap: the old TI holds z_bar, the old Bcur the inputs
+    }
+    __syncthreads();                          // z_bar of dense 0 published
+    if (tid < W) {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
+      real gx = 0, gt = 0, gb = 0;
+      for (int p = 0; p < 16; ++p) {
+        const V4 zb = Bcur[tid * PD + p];
+        gx += hxy[p] * zb.x + sx * zb.y;
+        gt += hxy[16 + p] * zb.x + st * zb.z;
+        gb += zb.x;
+      }
+      row[nd.off_w[0] + tid] += gx;
+      row[nd.off_w[0] + W + tid] += gt;
+      row[nd.off_b[0] + tid] += gb;
+    }
+    __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group
+  }
+  if (tid0 < 16) {   // loss parts, lambda gradients, output biases: sums over this workgroup's points
+    real l_acc[3], dl_acc[2], gb_acc[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) l_acc[k] = sum16(lsum[16 * k + tid0]);
+    dl_acc[0] = sum16(lsum[48 + tid0]); dl_acc[1] = sum16(lsum[64 + tid0]);
+    gb_acc[0] = sum16(lsum[80 + tid0]); gb_acc[1] = sum16(lsum[96 + tid0]);
+    if (tid0 == 0) {
+      row[nd.n_theta + 0] += l_acc[0]; row[nd.n_theta + 1] += l_acc[1]; row[nd.n_theta + 2] += l_acc[2];
+      row[nd.off_b[H]] += gb_acc[0];
+      if (NO > 1) row[nd.off_b[H] + 1] += gb_acc[1];
+      if (PDE == 1) { row[nd.n_net] += dl_acc[0]; row[nd.n_net + 1] += dl_acc[1]; }
+    }
+  }
+}
+
+}  // namespace pinn

@@ -17,7 +17,7 @@ _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 _REPO = os.path.dirname(os.path.dirname(_HERE))
 LIB_PATH = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "libpinn_hip.so")
 SOURCES = ["engine.hip", "fused20d_unit.hip", "fused20d_api.h", "fused20m_unit.hip", "fused20m_api.h", "kernels_generic.h", "kernels_fused20.h", "kernels_fused20m.h", "kernels_fused20d.h", "kernels_wide.h", "kernels_predict20.h",
-           "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
+           "kernels_disc.h", "kernels_sampling.h", "kernels_tile16.h", "kernels_tile16f.h", "kernels_xgmi.h", "kernels_optim.h", "wave.h"]
 HEADER = os.path.join(_REPO, "include", "pinn_hip.h")
 
 PDE_KINDS = {"burgers": 0, "burgers_ide": 1, "schrodinger": 2, "burgers_disc": 3, "burgers_disc_ide": 4}

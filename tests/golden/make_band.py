@@ -21,7 +21,12 @@ evidence, all written here:
   burgers_cfg1_band.json   BASELINE configs[0]: Adam x 2000 at lr 0.03, no L-BFGS (reference value 4.3073e-01):
                            printed log of the k = 0 run + the same ulp band
 
-    python3 tests/golden/make_band.py [cfg2] [cfg2_eps32] [prefix] [cfg1]
+  burgers_converged_band.json  the default Adam phase followed by L-BFGS for K_LONG iterations instead of 200 (the
+                           reference's own stopping tests, utils/custom_lbfgs.py:200-215, never fire before that:
+                           tolFun = eps on sum|g|, tolX = 1e-19): 5 members, k = 0, +-1, +-2 -- the one place where
+                           north_star's "final L2 within 1e-3" can be well-posed, if the long run converges
+
+    python3 tests/golden/make_band.py [cfg2] [cfg2_eps32] [prefix] [cfg1] [converged]
 """
 import json
 import os
@@ -37,6 +42,7 @@ import make_golden as mg  # noqa: E402
 K_ULP = [0, 1, -1, 2, 3, -2, -3, 4, -4] + [s * k for k in range(5, 13) for s in (1, -1)]   # configs[0] (76 s per run)
 K_ULP_CFG2 = K_ULP                              # configs[1] (15 s per run)
 EPS = 2.0 ** -52
+K_LONG = int(os.environ.get("PINN_BAND_K_LONG", "3000"))
 EPS32 = 2.0 ** -23                               # float32-sized perturbations (what the float32 engine is compared with)
 
 
@@ -109,7 +115,7 @@ def main():
     sys.path.insert(0, mg.SHIMS)
     sys.path.insert(1, os.path.join(mg.REF, "utils"))
     sys.path.insert(2, os.path.join(mg.REF, "1d-burgers"))
-    which = sys.argv[1:] or ["cfg2", "cfg2_eps32", "prefix", "cfg1"]
+    which = sys.argv[1:] or ["cfg2", "cfg2_eps32", "prefix", "cfg1", "converged"]
     if "cfg2" in which:
         band("burgers_band", mg.burgers_hp(tf_epochs=100, nt_epochs=200), "burgers_band_fields.npz", K_ULP_CFG2)
     if "cfg2_eps32" in which:
@@ -118,6 +124,9 @@ def main():
         band("burgers_band_eps32", mg.burgers_hp(tf_epochs=100, nt_epochs=200), None, K_ULP_CFG2, EPS32)
     if "prefix" in which:
         prefix()
+    if "converged" in which:
+        band("burgers_converged_band", mg.burgers_hp(tf_epochs=100, nt_epochs=K_LONG), "burgers_converged_fields.npz",
+             [0, 1, -1, 2, -2])
     if "cfg1" in which:
         band("burgers_cfg1_band", mg.burgers_hp(tf_epochs=2000, nt_epochs=0), "burgers_cfg1_fields.npz")
 

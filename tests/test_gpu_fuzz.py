@@ -20,6 +20,7 @@ def cases():
     rs = np.random.RandomState(2026)
     out = []
     fixed = [("burgers", 20, 8), ("burgers_ide", 20, 8), ("burgers", 20, 3), ("schrodinger", 100, 4),
+             ("burgers", 100, 4), ("burgers_ide", 65, 4), ("schrodinger", 128, 4),      # the fused float64 sweep (path 8)
              ("burgers", 1, 1), ("burgers", 128, 2), ("schrodinger", 24, 3), ("burgers_ide", 7, 11)]
     for pde, W, H in fixed:
         out.append((pde, W, H, int(rs.randint(1, 700)), int(rs.randint(1, 90)), int(rs.randint(0, 2 ** 31))))
@@ -61,7 +62,7 @@ def test_random_shapes_against_oracle(pde_kind, W, H, n_f, n_u, seed, dtype):
     tl, tg = (1e-11, 1e-10) if dtype == "f64" else (2e-5, 5e-5)
     default = eng.kernel_path()
     tried = 0
-    for path in (default, 0, 1, 2, 3, 4, 5, 6, 7):
+    for path in (default, 0, 1, 2, 3, 4, 5, 6, 7, 8):
         if tried and path == default:
             continue
         try:

@@ -535,3 +535,43 @@ def test_residual_at_arbitrary_points_matches_stored_set_and_oracle(burgers_sets
     _, _, ex = pde.burgers_loss_grad(w, layers, lb, ub, X_f, X_u, u, NU)
     assert np.max(np.abs(eng.residual_at(X_f) - ex["f"])) <= tol * max(np.max(np.abs(ex["f"])), 1.0)
     eng.close()
+
+
+@pytest.mark.parametrize("N_f", [20000, 50000])
+def test_fused_f64_sweep_of_the_schrodinger_net(schrodinger_sets, record, N_f):
+    """csrc/kernels_tile16f.h (kernel path 8, the engine's default for the Schrodinger net in float64): forward and
+    reverse sweep of a 16-point group in one kernel, stash in registers.  Against the two-kernel sweeps (path 4: the
+    same matrix-instruction and summation order -- agreement to the last few bits), the one-lane-per-point family
+    (path 0) and the oracle; bit-reproducible; N_f = 50000 spans two launches (partial rows accumulated across chunks)"""
+    from pinn_native import Engine
+    from oracle import pde
+    g = np.load(golden("schrodinger_eval.npz"))
+    hp = json.loads(str(g["hp"]))
+    r = schrodinger_sets(50, 50, N_f)
+    X_f, ub, lb, tb, x0, u0, v0, X0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17], r[18]
+    X_lb = np.concatenate((0 * tb + lb[0], tb), 1)
+    X_ub = np.concatenate((0 * tb + ub[0], tb), 1)
+    uv0 = np.concatenate([u0, v0], 1)
+    eng = Engine(hp["layers"], lb, ub, pde="schrodinger", dtype="f64")
+    assert eng.kernel_path() == 8
+    eng.set_collocation(X_f); eng.set_boundary(X_lb, X_ub); eng.set_data(X0, uv0)
+    rs = np.random.RandomState(7)
+    w = g["w0"] * (1.0 + 0.05 * rs.standard_normal(g["w0"].shape))
+    w[-2:] = 0.1, -0.2                                       # non-zero output biases
+    eng.set_weights(w)
+    l8, g8, t8 = eng.loss_grad()
+    l8b, g8b, _ = eng.loss_grad()
+    assert l8 == l8b and np.array_equal(g8, g8b)            # bit-reproducible
+    eng.set_kernel_path(4)
+    l4, g4, t4 = eng.loss_grad()
+    lo, go, _ = pde.schrodinger_loss_grad(w, hp["layers"], lb, ub, X_f, X_lb, X_ub, X0, uv0)
+    record(N_f=N_f, loss_vs_two_kernel=abs(l8 - l4) / abs(l4), grad_vs_two_kernel=rel(g8, g4),
+           loss_vs_oracle=abs(l8 - lo) / abs(lo), grad_vs_oracle=rel(g8, go), terms_vs_two_kernel=float(np.max(np.abs(t8 - t4))))
+    assert abs(l8 - l4) <= 1e-14 * abs(l4) and rel(g8, g4) <= 1e-13
+    assert abs(l8 - lo) <= 1e-12 * abs(lo) and rel(g8, go) <= 1e-11
+    if N_f == 20000:                                          # the golden evaluation (reference script over the shims)
+        eng.set_kernel_path(8)
+        eng.set_weights(g["w0"])
+        loss, grad, _ = eng.loss_grad()
+        assert abs(loss - float(g["loss_intent"])) / float(g["loss_intent"]) < 1e-12 and rel(grad, g["grad_intent"]) < 1e-11
+    eng.close()
