@@ -174,6 +174,10 @@ struct pinn_ctx {
   int lb_mode = 1, lb_mode_active = 0, lb_M1 = 0;
   double *lb_SY = nullptr, *lb_YY = nullptr, *lb_dots = nullptr, *lb_cs = nullptr, *lb_cy = nullptr;
   LbcExtra* lb_ex = nullptr;
+  unsigned int* t16_bsync = nullptr;   // k_t16_fused: boundary-group hand-over counter (never reset; t16_bcount = its value after the last launch)
+  unsigned int t16_bcount = 0;
+  double* t16_gscr = nullptr;          // k_t16_fused: tile-major weight-gradient scratch, one block per workgroup
+  size_t t16_gscr_bytes = 0;
 
   // collocation set generated on the device (pinn_lhs_collocation) instead of handed over
   struct { bool on = false; int64_t n_design = 0, first = 0, count = 0; uint64_t seed = 0; } lhs;
@@ -552,23 +556,40 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       bool fwd_done = false;
       if constexpr (sizeof(real) == 8) {
         if (c->path == 8) {
-          // periodic-boundary seeds read the outputs of a partner point another workgroup may own: the outputs of the
-          // boundary groups (the first 2 n_b points of the set) are produced by a forward sweep of their own first
-          if (PDE == 2 && base == 0 && sd.n_b > 0) {
-            const int bpts = (2 * sd.n_b + 15) / 16 * 16;
-            if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, 0, bpts < pts ? bpts : pts, lbx, lbt, sx, st)) return rc;
-          }
           static unsigned long long attr = 0;
           if (first_call_on_device(attr))
             HIPCHK(hipFuncSetAttribute((const void*)k_t16_fused<PDE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)t16_fused_lds()));
-          if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
           const int rows_cap = t16_wgs(c, c->chunk);
           const int wgs = t16_wgs(c, pts) < rows_cap ? t16_wgs(c, pts) : rows_cap;
+          // periodic-boundary seeds read the outputs of a partner point another workgroup may own.  The boundary points
+          // fill the first groups of the set: when each of them is the first group of its workgroup the kernel hands
+          // the outputs over itself (kernels_tile16f.h); otherwise a forward sweep over those groups runs first
+          int n_bg = (PDE == 2 && base == 0 && sd.n_b > 0) ? (2 * sd.n_b + 15) / 16 : 0;
+          if (n_bg > wgs) {
+            if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, 0, 16 * n_bg < pts ? 16 * n_bg : pts, lbx, lbt, sx, st)) return rc;
+            n_bg = 0;
+          }
+          if (!c->t16_bsync) {
+            if (dev_alloc(&c->t16_bsync, 64)) return PINN_EHIP;
+            HIPCHK(hipMemsetAsync(c->t16_bsync, 0, 64, c->stream));
+            c->t16_bcount = 0;
+          }
+          c->t16_bcount += (unsigned int)n_bg;
+          {  // tile-major scratch of the hidden-layer weight gradients: one block per workgroup (kernels_tile16f.h)
+            const size_t ntl = ((size_t)c->nd.width + 15) / 16;
+            const size_t need = (size_t)rows_cap * (c->nd.n_hidden - 1) * ntl * ntl * 256 * sizeof(double);
+            if (need > c->t16_gscr_bytes) {
+              if (dev_alloc(&c->t16_gscr, need)) return PINN_EHIP;
+              c->t16_gscr_bytes = need;
+            }
+          }
+          if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
           hipLaunchKernelGGL((k_t16_fused<PDE, 4>), dim3(wgs), dim3(512), t16_fused_lds(), c->stream, c->nd, sd,
                              (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, (const double*)c->tgt,
                              base, sd.n_pad, pts / 16, (double)lbx, (double)lbt, (double)sx, (double)st, (double)c->nu,
-                             (vec4<double>*)c->O, (double*)c->part, c->R, ci > 0 ? 1 : 0);
+                             (vec4<double>*)c->O, (double*)c->part, c->R, ci > 0 ? 1 : 0, c->t16_bsync, c->t16_bcount, n_bg,
+                             c->t16_gscr);
           HIPCHK(hipGetLastError());
           continue;
         }
@@ -1116,7 +1137,7 @@ int pinn_destroy(pinn_ctx* c) {
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp,
-                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite};
+                  c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite, c->t16_bsync, c->t16_gscr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
   if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
                                                    const double* __restrict__ tgt, int base, int n_pad, int n_groups,
                                                    double lbx, double lbt, double sx, double st, double nu,
                                                    vec4<double>* __restrict__ O, double* __restrict__ part, int R,
-                                                   int accumulate) {
+                                                   int accumulate, unsigned int* __restrict__ bsync,
+                                                   unsigned int btarget, int n_bgroups, double* __restrict__ gscr) {
   using real = double;
   using TR = FusedTraits<double>;
   using acc_t = typename TR::acc_t;
@@ -67,6 +68,14 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   const int ksteps = (W + 3) / 4, nchunks = (ksteps + 3) >> 2;
   const bool tile_live = 16 * wave < W;                           // wave-uniform: this wave's feature tile has real rows
   real* __restrict__ row = part + (size_t)blockIdx.x * R;
+  // Hidden-to-hidden weight gradients are accumulated over the workgroup's groups in a TILE-MAJOR scratch of its own
+  // (per layer and gradient tile: the 64 lanes' four accumulator values, 2 KB contiguous, whole cache lines read and
+  // written) and copied into the partial row once at the end.  Adding each tile into the row directly (k_t16_bwd)
+  // touches 16-double segments at an 800-byte row pitch: every segment straddles two cache lines and is written
+  // partially -- profiles/r04_pmc_fetch_write_cfg4.txt: 295 MB fetched (raw) / 366 MB written for 315 MB of entries,
+  // and 70 of 520 us in this kernel (profiles/r04_ablate_t16_fused_v2.txt).
+  const int ntl = (W + 15) >> 4, n_tiles = ntl * ntl;             // live gradient tiles per side / per layer
+  real* __restrict__ gs = gscr + (size_t)blockIdx.x * (H - 1) * n_tiles * 256;
   real c1 = real(1), c2 = nu;
   if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp_r(th[nd.n_net + 1]); }
 
@@ -204,7 +213,27 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         O[(size_t)o * n_pad + base + lp0 + pe] = tot;
       }
     }
-    __syncthreads();                          // the group's outputs are in memory (written and read by this workgroup)
+    if (grp < n_bgroups) {
+      // Periodic-boundary seeds read the outputs of a PARTNER point, which another workgroup may own.  The boundary
+      // points fill the first n_bgroups groups of the set, each the FIRST group of its workgroup (grid >= n_bgroups,
+      // checked by the host), so those workgroups are co-resident and reach this point without waiting for anybody:
+      // publish (fence + counter), wait until all n_bgroups groups of this launch are published (the counter is
+      // never reset: btarget = its value after this launch), then drop this CU's L1 so the partners' outputs are
+      // read from L2.  Bounded: a lost partner costs a fraction of a second and wrong seeds, never a hang.
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) {
+        atomicAdd(bsync, 1u);
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          if ((int)(__hip_atomic_load(bsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - btarget) >= 0) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {
+      __syncthreads();                        // the group's outputs are in memory (written and read by this workgroup)
+    }
     // =========================================================================================== reverse sweep
     if (tid < 16) {
       const int pt = base + lp0 + tid;
@@ -249,22 +278,37 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         Bcur[j * PD + m] = zb;
       }
     }
+    // Weight-gradient tiles of a layer, dealt so that every SIMD carries the same number of matrix instructions: a
+    // wave whose feature tile is live also runs the adjoint GEMM (ksteps x 4 instructions = ge tile-equivalents), a
+    // wave without one (width 100: wave 7) takes that many more gradient tiles.  Contiguous ranges [t_lo, t_hi).
+    int t_lo, t_hi;
+    {
+      const int ge = (ksteps * 4 + 8) / 16, idle = NWV - ntl;
+      int per_idle = idle > 0 ? (n_tiles + ntl * ge + NWV - 1) / NWV : 0;
+      if (per_idle * idle > n_tiles) per_idle = n_tiles / (idle > 0 ? idle : 1);
+      const int rest = n_tiles - per_idle * idle, base_n = rest / ntl, extra = rest - base_n * ntl;
+      if (wave < ntl) { t_lo = wave * base_n + (wave < extra ? wave : extra); t_hi = t_lo + base_n + (wave < extra ? 1 : 0); }
+      else { t_lo = rest + (wave - ntl) * per_idle; t_hi = t_lo + per_idle; }
+    }
 #pragma unroll
     for (int d = H - 1; d >= 1; --d) {
       __syncthreads();                        // Bcur (z_bar of layer d), TI (inputs of layer d) published
-      // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j
-      const int ntl = (W + 15) >> 4;                              // live tiles per side: the others are padding
-      for (int tau = wave; tau < ntl * ntl; tau += NWV) {
+      // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j.
+      // The row entries of the NEXT tile are requested before this tile's matrix instructions (a fetch from the
+      // 63 MB of partial rows costs 2-3 k cycles, a tile's 16 matrix instructions last 1 k)
+      const bool fresh = grp == (int)blockIdx.x;   // this workgroup's first group of the launch: the scratch starts here
+      V4* __restrict__ gsd = reinterpret_cast<V4*>(gs + (size_t)(d - 1) * n_tiles * 256) + lane;
+      auto fetch_old = [&](const int tau) {
+#if T16_ABL == 3
+        return V4{0, 0, 0, 0};
+#else
+        return (tau < t_hi && !fresh) ? gsd[(size_t)tau * 64] : V4{0, 0, 0, 0};
+#endif
+      };
+      V4 old = fetch_old(t_lo);
+      for (int tau = t_lo; tau < t_hi; ++tau) {
         const int rt = tau / ntl, ct = tau - rt * ntl;
-        const int j = 16 * ct + m;
-        real old[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * rt + TR::out_row(lane, r);
-          // the first group of a fresh row adds to the zeros this workgroup has just written: nothing to fetch
-          old[r] = (k < W && j < W && !(T16_SKIP_FIRST && !accumulate && grp == (int)blockIdx.x))
-                       ? row[nd.off_w[d] + k * W + j] : real(0);
-        }
+        const V4 nxt = fetch_old(tau + 1);
         acc_t acc = {0, 0, 0, 0};
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -274,38 +318,37 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
           acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * rt + TR::out_row(lane, r);
-          if (k < W && j < W) row[nd.off_w[d] + k * W + j] = old[r] + acc[r];
-        }
+#if T16_ABL == 3
+        if (acc[0] == real(-1.2345e300)) gsd[(size_t)tau * 64] = V4{acc[0], acc[1], acc[2], acc[3]};
+#else
+        gsd[(size_t)tau * 64] = V4{old.x + acc[0], old.y + acc[1], old.z + acc[2], old.w + acc[3]};
+#endif
+        old = nxt;
       }
       if (tid < W) {                          // bias gradient of layer d
         real sb_ = 0;
         for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
         row[nd.off_b[d] + tid] += sb_;
       }
-      __syncthreads();                        // every wave is done reading TI (dW): it becomes the output tile
-      // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p], then straight through its tanh
-      V4* const Bnxt = TI;
-      if (!tile_live) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Bnxt[(16 * wave + TR::out_row(lane, r)) * PD + m] = V4{0, 0, 0, 0};
-      } else {
-        acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
-        gemm(th + nd.off_w[d], Bcur, std::true_type{}, a0, a1, a2, a3);
+      // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p] into registers -- no barrier between the
+      // gradient tiles and this GEMM (both only READ the two tiles), so the waves of a SIMD drift apart and one's
+      // matrix instructions run under the other's loads and stores
+      acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+      if (tile_live) gemm(th + nd.off_w[d], Bcur, std::true_type{}, a0, a1, a2, a3);
+      __syncthreads();                        // every wave is done reading TI and Bcur: both are rewritten
+      {  // ... straight through layer d-1's tanh into TI (the next layer's z_bar)
+        V4* const Bnxt = TI;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int k = 16 * wave + TR::out_row(lane, r);
           V4 v{0, 0, 0, 0};
-          if (k < W) {
+          if (tile_live && k < W) {
             const V4 sk = d >= 2 ? stash[d >= 2 ? d - 2 : 0][r] : dense0(k, hxy[m], hxy[16 + m]);
             v = preact_adjoint(sk, V4{a0[r], a1[r], a2[r], a3[r]});
           }
           Bnxt[k * PD + m] = v;
         }
       }
-      __syncthreads();                        // every wave is done reading Bcur (adjoint GEMM): it is refilled
       if (d >= 2) {                           // inputs of layer d-1 = output channels of layer d-2
         if (d >= 3) {                         // ... from the owning lanes' registers
 #pragma unroll
@@ -345,6 +388,19 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       row[nd.off_b[0] + tid] += gb;
     }
     __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group
+  }
+  {  // tile-major scratch -> the partial row (every entry written by the lane that owns it: no barrier needed)
+    const int lane = tid0 & 63, m = lane & 15;
+    for (int e = wave; e < (H - 1) * n_tiles; e += NWV) {
+      const int dl = e / n_tiles, tau = e - dl * n_tiles, rt = tau / ntl, ct = tau - rt * ntl, j = 16 * ct + m;
+      const V4 v = reinterpret_cast<const V4*>(gs)[(size_t)e * 64 + lane];
+      const real vr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * rt + TR::out_row(lane, r);
+        if (k < W && j < W) row[nd.off_w[dl + 1] + k * W + j] += vr[r];      // (+ the zeros / the earlier chunks' sums)
+      }
+    }
   }
   if (tid0 < 16) {   // loss parts, lambda gradients, output biases: sums over this workgroup's points
     real l_acc[3], dl_acc[2], gb_acc[2];

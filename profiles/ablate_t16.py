@@ -13,7 +13,7 @@ NAMES = {0: "product kernels", 1: "no stash traffic (S stores / loads)", 2: "no 
 def build(d):
     os.makedirs(d, exist_ok=True)
     hipcc = "/opt/rocm/bin/hipcc"
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC"]
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
     procs = [(n, subprocess.Popen(common + ["-DT16_ABL=%d" % n, "-c", os.path.join(PKG, "csrc", "engine.hip"), "-o",
                                             os.path.join(d, "engine_t16abl%d.o" % n)],
                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)) for n in NAMES]
@@ -49,11 +49,13 @@ for n in NAMES:
     if dbs:
         con = sqlite3.connect(dbs[0])
         for name, avg in con.execute("select name, avg(end - start) from kernels group by name"):   # the `kernels` view of rocpd
-            for key in ("k_t16_fwd", "k_t16_bwd"):
+            for key in ("k_t16_fwd", "k_t16_bwd", "k_t16_fused"):
                 if key in name:
                     t[key] = avg / 1e3
     if n == 0:
         base = dict(t)
-    print("%d %-52s fwd %7.1f us (%+7.1f)   bwd %7.1f us (%+7.1f)   %s" % (
+    print("%d %-52s fwd %7.1f us (%+7.1f)   bwd %7.1f us (%+7.1f)   fused %7.1f us (%+7.1f)   %s" % (
         n, NAMES[n], t.get("k_t16_fwd", float("nan")), t.get("k_t16_fwd", 0) - base.get("k_t16_fwd", 0),
-        t.get("k_t16_bwd", float("nan")), t.get("k_t16_bwd", 0) - base.get("k_t16_bwd", 0), step[0].split(":")[1].split("->")[0] if step else "?"), flush=True)
+        t.get("k_t16_bwd", float("nan")), t.get("k_t16_bwd", 0) - base.get("k_t16_bwd", 0),
+        t.get("k_t16_fused", float("nan")), t.get("k_t16_fused", 0) - base.get("k_t16_fused", 0),
+        step[0].split(":")[1].split("->")[0] if step else "?"), flush=True)
