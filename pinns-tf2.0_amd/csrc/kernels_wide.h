@@ -356,18 +356,24 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
 #pragma unroll
   for (int o = 0; o < NO; ++o) gbL[o] = 0.0f;
 
-  auto feat = [&](int t, int r) { return 16 * (wave + 4 * t) + 4 * g + r; };
-  auto load_stash = [&](v4f (&dst)[2][4], int d, int lp) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = feat(t, r);
-        dst[t][r] = j < W ? Sv[((size_t)d * W + j) * s_pad + lp] : v4f{0, 0, 0, 0};
-      }
-  };
-
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // the lane index is re-read through an opaque asm once per group: every per-lane address of the body is
+    // loop-invariant, hipcc hoisted them out of the group loop and the 512-register wave spilled 54 of them (220 B of
+    // scratch per lane, rounds 1-3); recomputed per group they cost a few integer instructions and no scratch
+    int lane_o = tid & 63;
+    asm volatile("" : "+v"(lane_o));
+    const int lane = lane_o, n = lane_o & 15, g = lane_o >> 4;
+  auto feat = [&](int t, int r) { return 16 * (wave + 4 * t) + 4 * g + r; };
+    auto load_stash = [&](v4f (&dst)[2][4], int d, int lp) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * (wave + 4 * t) + 4 * (lane >> 4) + r;
+          dst[t][r] = j < W ? Sv[((size_t)d * W + j) * s_pad + lp] : v4f{0, 0, 0, 0};
+        }
+    };
+
     const int lp = grp * 16 + n, pt = base + lp;
     const float x = xs[pt], t_ = ts[pt];
     const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t_ - lbt, -1.0f);
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256) void k_wide_bwd(NetDesc nd, SetDesc sd, const 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j = feat(t, r);
+      const int j = 16 * (wave + 4 * t) + 4 * (lane >> 4) + r;
       const float a = row16_sum(agpr_get(g0x[t][r])), b = row16_sum(agpr_get(g0t[t][r])),
                   c = row16_sum(agpr_get(g0b[t][r]));
       float e[NO];
