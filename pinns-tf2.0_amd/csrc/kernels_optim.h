@@ -485,6 +485,7 @@ __device__ long long g_coef_stamps[16];         // s_memtime timeline of the las
 #define CSTAMP(i) do { } while (0)
 #endif
 inline int lbc_ld(int M1) { return M1 | 1; }     // odd leading dimension: column walks hit distinct banks
+static_assert((62 | 1) <= 62 + 1 && 64 - 1 < 6 * 64, "k_lbc_coef_apply: unclamped column reads stay inside initialised LDS");
 constexpr int LBC_MAXSLOTS = 62;                  // one lane per ring slot
 
 // k_lbc_coef_apply: the scalar two-loop recursion AND the vector update in ONE launch.
@@ -679,6 +680,12 @@ __global__ __launch_bounds__(LBC_THREADS) void k_lbc_coef_apply(
     // broadcast; fetched in a block ahead of the chain they cost ~40 ticks per step).  Column indices run to
     // 8 * NCH - 1 = 63 without a clamp (immediate offsets): beyond M1 they read the pad column (zeroed above), the
     // first elements of the next row or of the next staged array -- finite values, multiplied by a lane that holds 0.
+    // What that rests on: (1) LD = lbc_ld(M1) = M1 | 1 <= M1 + 1, so a row's overrun [M1, 64) lands in the
+    // following rows of the SAME matrix, all of whose cells (pad column included) are written while staging; (2) the
+    // staging order sU, sL, sY, sT: the overrun of a matrix's last rows lands in the next matrix, and that of sY in
+    // sT, whose 6 x 64 entries are all written (zeros for lanes >= M1) -- 64 - M1 <= 63 < 384; (3) every staged value
+    // is finite whenever the history is (ro = 1 / y.s with y.s > 1e-10): a non-finite history has already made the
+    // loss non-finite (pinn_get_status reports it), a product 0 x Inf here changes nothing that was still valid.
     double ub[2][8], yb[2][8];
 #pragma unroll
     for (int c8 = NCH - 1; c8 >= 0; --c8) {

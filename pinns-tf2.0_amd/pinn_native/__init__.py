@@ -85,7 +85,11 @@ def build(force=False, verbose=False, stamps=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise PinnNativeError("hipcc not found; cannot build libpinn_hip.so")
-    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+    try:
+        lock = open(os.path.join(_HERE, ".build.lock"), "w")
+    except OSError as e:                          # a read-only install: nothing can be built in place
+        raise PinnNativeError("cannot build in %s (%s); build the library where the tree is writable" % (_HERE, e))
+    with lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not stamps and not _stale():        # another process built it while we waited
             return LIB_PATH
@@ -207,9 +211,12 @@ def load():
     if not os.environ.get("PINN_HIP_LIB") and _stale():     # an explicitly named library (a variant build) is used as it is
         try:
             build()
-        except PinnNativeError:
+        except PinnNativeError as e:
             if not os.path.exists(LIB_PATH):
                 raise
+            import warnings
+            warnings.warn("libpinn_hip.so is older than its sources and could not be rebuilt (%s): using the stale "
+                          "library" % str(e).splitlines()[0], RuntimeWarning)
     if not os.path.exists(LIB_PATH):
         raise PinnNativeError(
             "libpinn_hip.so is missing (%s): run `python -c 'import __graft_entry__ as g; "
