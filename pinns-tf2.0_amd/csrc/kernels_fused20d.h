@@ -39,6 +39,13 @@
 #include "kernels_fused20.h"
 #include "fused20d_api.h"
 
+// 1: the tile loop re-reads the lane index through an opaque asm once per tile (what stopped the address hoisting of
+// k_wide_bwd / k_t16_fused).  Here it takes the tile-loop variants from 256 VGPRs + 6-11 AGPR spill slots to 238-242 / 0
+// and is 1 % SLOWER (same-box A/B, N_f = 10^6: 1991 / 2000 vs 1971 / 1978 us per Adam step): off.
+#ifndef PINN_OPAQUE_TILE_D
+#define PINN_OPAQUE_TILE_D 0
+#endif
+
 namespace pinn {
 
 // Ablation builds (profiles/ablate_fused20d.py, -DPINN_ABLD=n): one ingredient of k_fused20d compiled out at a time --
@@ -166,16 +173,23 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
 
   STAMP(0);
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int q = lane & 15;                 // point of this wave's 16
-  const int s = lane >> 4;                 // feature slot: feature = 4 * group + s
-  const int i4 = lane & 3;                 // row / column slot of the A patterns and of the gradient blocks
-  const int pf = s * FW + i4;              // forward pattern:  W[4m + s][4n + i4]
-  const int pr = i4 * FW + s;              // reverse pattern:  W[4m + i4][4n + s]
-  const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   // lane-index rotation by two bits (bpermute address)
+  // per-lane indices as a macro: the tile loop re-derives them from an opaque copy of the lane index once per tile
+  // (PINN_OPAQUE_LANE), so that hipcc does not carry the ~30 per-lane LDS addresses they feed across the loop
+#define PINN_LANE_INDICES(L)                                                                                          \
+  const int lane = (L);                                                                                                \
+  const int q = lane & 15;                 /* point of this wave's 16 */                                              \
+  const int s = lane >> 4;                 /* feature slot: feature = 4 * group + s */                                \
+  const int i4 = lane & 3;                 /* row / column slot of the A patterns and of the gradient blocks */       \
+  const int pf = s * FW + i4;              /* forward pattern:  W[4m + s][4n + i4] */                                 \
+  const int pr = i4 * FW + s;              /* reverse pattern:  W[4m + i4][4n + s] */                                 \
+  const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   /* lane-index rotation by two bits (bpermute address) */ \
+  const int ge = s * 4 + i4;               /* this lane's entry (i, j) of a gradient block */                         \
+  double* const lacc = gacc_all + 4 * NBLK * 16 + wave * 256 + lane;       /* [k * 64]: l_res, l_dat, dl0, dl1 */     \
+  const double onesA = i4 == 0 ? 1.0 : 0.0;                     /* rotated "ones" in-group: row 0 = 1 (bias gradients) */ \
+  (void)q; (void)pf; (void)pr; (void)rot4; (void)ge; (void)lacc; (void)onesA; (void)s
+  PINN_LANE_INDICES(tid & 63);
   double* const gacc = gacc_all + wave * (NBLK * 16);
-  const int ge = s * 4 + i4;               // this lane's entry (i, j) of a gradient block; shared by its four b-lanes
 
   // first tile's coordinates: issued ahead of the weight staging, so the two round trips overlap
   int tile = blockIdx.x;
@@ -201,8 +215,6 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   // per-lane partial sums of the loss parts and of the two lambda gradients (slot-0 lanes only) live in LDS, four
   // slots per lane behind the gradient accumulators: one read-modify-write per tile instead of eight registers held
   // across the whole kernel (which cost the identification variant 20 B of scratch per lane)
-  double* const lacc = gacc_all + 4 * NBLK * 16 + wave * 256 + lane;       // [k * 64]: l_res, l_dat, dl0, dl1
-  const double onesA = i4 == 0 ? 1.0 : 0.0;                     // rotated "ones" in-group: row 0 = 1 (bias gradients)
 
   // Gradient blocks.  D = this lane's partial sum over the four points of its block b; the four blocks of an entry
   // are folded with two DPP row rotations -- commutative, so the four lanes of an entry end with bit-identical
@@ -210,19 +222,6 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   // are fetched BEFORE the matrix instructions that produce D (grad_fetch), so no LDS round trip is exposed.
 #if PINN_ABLD == 1 || PINN_ABLD == 2
   double abl_sink = 0.0;
-  auto grad_fetch = [&](const int) { return 0.0; };
-  auto grad_store = [&](double D, const double, const int) {
-#if PINN_ABLD == 1
-    abl_sink += D;                               // keeps the matrix instructions, drops fold and accumulate
-#endif
-  };
-#else
-  auto grad_fetch = [&](const int blk) { return ONE_TILE ? 0.0 : gacc[blk * 16 + ge]; };
-  auto grad_store = [&](double D, const double old, const int blk) {
-    D += dpp_mov<DPP_ROW_ROR8>(D);
-    D += dpp_mov<DPP_ROW_ROR4>(D);
-    gacc[blk * 16 + ge] = ONE_TILE ? D : old + D;
-  };
 #endif
   // (Tried: ds_add_f64 with the four lanes of an entry hitting one address, no fold, no read-modify-write --
   //  221 instructions instead of ~3000, bit-reproducible over 200 runs, and 14 % SLOWER: 49.8 vs 43.7 us per step.)
@@ -230,6 +229,25 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   STAMP(1);
 
   for (; tile < n_tiles; tile += gridDim.x) {
+    // (PINN_OPAQUE_TILE_D, off by default: see the macro)
+    int lane_o = tid & 63;
+    if (!ONE_TILE && PINN_OPAQUE_TILE_D) asm volatile("" : "+v"(lane_o));
+    PINN_LANE_INDICES(lane_o);
+#if PINN_ABLD == 1 || PINN_ABLD == 2
+    auto grad_fetch = [&](const int) { return 0.0; };
+    auto grad_store = [&](double D, const double, const int) {
+#if PINN_ABLD == 1
+      abl_sink += D;                               // keeps the matrix instructions, drops fold and accumulate
+#endif
+    };
+#else
+    auto grad_fetch = [&](const int blk) { return ONE_TILE ? 0.0 : gacc[blk * 16 + ge]; };
+    auto grad_store = [&](double D, const double old, const int blk) {
+      D += dpp_mov<DPP_ROW_ROR8>(D);
+      D += dpp_mov<DPP_ROW_ROR4>(D);
+      gacc[blk * 16 + ge] = ONE_TILE ? D : old + D;
+    };
+#endif
     const int pt = tile * 64 + wave * 16 + q;
     const double hx = __builtin_fma(sx, x - lbx, -1.0), ht = __builtin_fma(st, t - lbt, -1.0);
     {
@@ -445,6 +463,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     if (ONE_TILE) break;
   }
   STAMP(2 * H + 1);
+#undef PINN_LANE_INDICES
 
   // -------------------------------------------------------------------- one gradient row per workgroup
   {

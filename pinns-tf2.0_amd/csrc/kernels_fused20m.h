@@ -39,6 +39,13 @@
 #include <hip/hip_ext.h>
 #include "kernels_fused20.h"
 
+// 1: the tile loop re-reads the lane index through an opaque asm once per tile, so that hipcc does not carry the LDS
+// addresses it feeds across the loop: same-box A/B at N_f = 10^6 1307 / 1316 vs 1333 / 1337 us per Adam step (-1.7 %),
+// the 10-layer tile-loop variant's scratch 216 -> 136 B per lane
+#ifndef PINN_OPAQUE_TILE_M
+#define PINN_OPAQUE_TILE_M 1
+#endif
+
 namespace pinn {
 
 // Ablation builds (profiles/ablate_fused20m.py, -DPINN_ABL=n): one ingredient of k_fused20m compiled out at a time --
@@ -315,19 +322,28 @@ __global__ PINN_F20M_BOUNDS void k_fused20m(const float* __restrict__ th, const 
 
   // main block operands: A row = input feature lane%16, B column = output feature lane%16,
   // lane group q = lane/16 supplies point 16q + 4w + jj at step jj
-  const int mrow = (lane & 15) * RS4 + (lane >> 4) * 16 + 4 * wave;
   // fringe block b = lane/4 -> (input-feature group kg, output-feature group jg):
   //   b 0..3: (4, b)   b 4..7: (5 = ones row, b-4)   b 8..11: (b-8, 4)   b 12: (4, 4)   b 13..15: (5, 4)
-  const int fblk = lane >> 2;
-  const int fkg = fblk < 4 ? 4 : fblk < 8 ? 5 : fblk < 12 ? fblk - 8 : fblk == 12 ? 4 : 5;
-  const int fjg = fblk < 8 ? (fblk & 3) : 4;
-  const int farow = min(4 * fkg + (lane & 3), FW) * RS4 + 16 * wave;     // rows past the ones row repeat it
-  const int fbrow = (4 * fjg + (lane & 3)) * RS4 + 16 * wave;
-  const int qw = 4 * lane + wave;                             // float index of (point, channel = wave) in a Q row
+  // (a macro: the tile loop re-derives these from an opaque copy of the lane index once per tile, see there)
+#define PINN_LANE_INDICES_M(L)                                                                                        \
+  const int lane = (L);                                                                                                \
+  const int mrow = (lane & 15) * RS4 + (lane >> 4) * 16 + 4 * wave;                                                    \
+  const int fblk = lane >> 2;                                                                                          \
+  const int fkg = fblk < 4 ? 4 : fblk < 8 ? 5 : fblk < 12 ? fblk - 8 : fblk == 12 ? 4 : 5;                             \
+  const int fjg = fblk < 8 ? (fblk & 3) : 4;                                                                           \
+  const int farow = min(4 * fkg + (lane & 3), FW) * RS4 + 16 * wave;     /* rows past the ones row repeat it */        \
+  const int fbrow = (4 * fjg + (lane & 3)) * RS4 + 16 * wave;                                                          \
+  const int qw = 4 * lane + wave;                             /* float index of (point, channel = wave) in a Q row */  \
+  (void)mrow; (void)farow; (void)fbrow; (void)qw; (void)fkg; (void)fjg; (void)fblk
   STAMP(1);
   bool image_pending = true;
 
   for (; tile < n_tiles; tile += gridDim.x) {
+    // tile loop: lane index re-read through an opaque asm once per tile, per-lane indices re-derived -- keeps hipcc from
+    // carrying the LDS addresses they feed across the loop (kernels_fused20d.h; the 10-layer tile-loop variant spilled)
+    int lane_o = tid & 63;
+    if (!ONE_TILE && PINN_OPAQUE_TILE_M) asm volatile("" : "+v"(lane_o));
+    PINN_LANE_INDICES_M(lane_o);
     const int pt = tile * 64 + lane;
     const float hx = fmaf(sx, x - lbx, -1.0f), ht = fmaf(st, t - lbt, -1.0f);
     {  // next tile's coordinates: in flight during this tile
@@ -618,6 +634,7 @@ __global__ PINN_F20M_BOUNDS void k_fused20m(const float* __restrict__ th, const 
     lds_barrier();
 #if PINN_ABL != 8
     const int km = 4 * (lane >> 4), jm = lane & 15;              // main block: VGPR r -> input feature km + r
+    PINN_LANE_INDICES_M(tid & 63);
     const int kf = 4 * fkg, jf = 4 * fjg + (lane & 3);           // fringe block: VGPR r -> input feature kf + r
     const bool okf = fblk <= 13;
 #pragma unroll
