@@ -2,7 +2,7 @@
 // forward and the reverse sweep of a 16-point group in ONE kernel and the stash in registers -- no HBM stash.
 //
 // Why (BASELINE configs[3]: the Schrodinger net 2-100x4-2 in the reference's arithmetic, N_f = 20000).  The two-kernel
-// sweeps move 1.25 GB per evaluation for 0.3 MB of coordinates (profiles/r04_pmc_fetch_write_cfg4.txt): k_t16_fwd writes
+// sweeps move 1.25 GB per evaluation for 0.3 MB of coordinates (profiles/r04_pmc_fetch_write_cfg4_two_kernel.txt): k_t16_fwd writes
 // the 6.4 KB/point stash (253 MB), k_t16_bwd reads it back and read-modify-writes the 246 KB gradient row of its
 // workgroup once per group (295 MB raw fetched, 366 MB written); ablation (profiles/r03_ablate_t16_f64_w8.txt): stash
 // stores / loads -16 / -64 us, row read-modify-write -83 us of 583.
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   // (per layer and gradient tile: the 64 lanes' four accumulator values, 2 KB contiguous, whole cache lines read and
   // written) and copied into the partial row once at the end.  Adding each tile into the row directly (k_t16_bwd)
   // touches 16-double segments at an 800-byte row pitch: every segment straddles two cache lines and is written
-  // partially -- profiles/r04_pmc_fetch_write_cfg4.txt: 295 MB fetched (raw) / 366 MB written for 315 MB of entries,
-  // and 70 of 520 us in this kernel (profiles/r04_ablate_t16_fused_v2.txt).
+  // partially -- profiles/r04_pmc_fetch_write_cfg4_two_kernel.txt: 295 MB fetched (raw) / 366 MB written for 315 MB of entries,
+  // and 70 of 520 us in this kernel (profiles/r04_ablate_t16_fused_v3.txt: 70 us before, 21 us with the scratch).
   const int ntl = (W + 15) >> 4, n_tiles = ntl * ntl;             // live gradient tiles per side / per layer
   real* __restrict__ gs = gscr + (size_t)blockIdx.x * (H - 1) * n_tiles * 256;
   real c1 = real(1), c2 = nu;
