@@ -194,7 +194,7 @@ int pinn_sync(pinn_ctx* c);
  * 2 fused 8x20 float32 (MFMA GEMVs, register stash), 3 wide MFMA sweeps (width 100, two outputs, float32),
  * 4 shape-generic MFMA sweeps (any width <= 128 / 64 in float64, any depth), 5 / 6 = 4's forward / reverse half
  * paired with the generic other half (tests), 7 fused 8x20 float64 (v_mfma_f64_4x4x4 GEMVs, register stash, no
- * inter-wave exchange), 8 fused float64 MFMA sweep for hidden widths 65..128 and 4 hidden layers (forward + reverse of a
+ * inter-wave exchange), 8 fused float64 MFMA sweep for hidden widths 65..128 and 2-4 hidden layers (forward + reverse of a
  * 16-point group in one kernel, stash in registers: the Schrodinger net in the reference's arithmetic).  The engine
  * picks the fastest eligible family at pinn_create. */
 int pinn_set_kernel_path(pinn_ctx* c, int path);

@@ -249,7 +249,7 @@ static bool wide_ok(const pinn_ctx* c) {
 static bool tile16_ok(const pinn_ctx* c) { return !is_disc(c) && c->nd.width <= 128 && c->nd.n_out <= 2; }
 // the fused float64 sweep (kernels_tile16f.h): forward + reverse of a group in one kernel, stash in registers
 static bool t16_fused_ok(const pinn_ctx* c) {
-  return tile16_ok(c) && c->dtype == PINN_F64 && c->nd.width > 64 && c->nd.n_hidden == 4;
+  return tile16_ok(c) && c->dtype == PINN_F64 && c->nd.width > 64 && c->nd.n_hidden >= 2 && c->nd.n_hidden <= 4;
 }
 static bool t16_fwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 5; }
 static bool t16_bwd_on(const pinn_ctx* c) { return c->path == 4 || c->path == 6 || c->path == 8; }   // (one partial row per workgroup, t16_wgs)
@@ -512,6 +512,21 @@ static int t16_bwd(pinn_ctx* c, int base, int pts, real lbx, real lbt, real sx, 
   return t16_launch_bwd<real, 4, PDE, true>(c, base, pts, lbx, lbt, sx, st, accumulate);
 }
 
+template <int PDE, int H>
+static int t16_fused_launch(pinn_ctx* c, const SetDesc& sd, int base, int pts, int ci, int wgs, int n_bg, double lbx,
+                            double lbt, double sx, double st) {
+  static unsigned long long attr = 0;
+  if (first_call_on_device(attr))
+    HIPCHK(hipFuncSetAttribute((const void*)k_t16_fused<PDE, H>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)t16_fused_lds()));
+  hipLaunchKernelGGL((k_t16_fused<PDE, H>), dim3(wgs), dim3(512), t16_fused_lds(), c->stream, c->nd, sd,
+                     (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, (const double*)c->tgt, base,
+                     sd.n_pad, pts / 16, lbx, lbt, sx, st, (double)c->nu, (vec4<double>*)c->O, (double*)c->part, c->R,
+                     ci > 0 ? 1 : 0, c->t16_bsync, c->t16_bcount, n_bg, c->t16_gscr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 template <typename real, int PDE>
 static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
   constexpr int JT = sizeof(real) == 4 ? 20 : 10;
@@ -556,10 +571,6 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
       bool fwd_done = false;
       if constexpr (sizeof(real) == 8) {
         if (c->path == 8) {
-          static unsigned long long attr = 0;
-          if (first_call_on_device(attr))
-            HIPCHK(hipFuncSetAttribute((const void*)k_t16_fused<PDE, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)t16_fused_lds()));
           const int rows_cap = t16_wgs(c, c->chunk);
           const int wgs = t16_wgs(c, pts) < rows_cap ? t16_wgs(c, pts) : rows_cap;
           // periodic-boundary seeds read the outputs of a partner point another workgroup may own.  The boundary points
@@ -585,12 +596,13 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
             }
           }
           if (ev4 && ci == 0) HIPCHK(hipEventRecord(ev4[1], c->stream));
-          hipLaunchKernelGGL((k_t16_fused<PDE, 4>), dim3(wgs), dim3(512), t16_fused_lds(), c->stream, c->nd, sd,
-                             (const double*)c->theta_r, (const double*)c->xs, (const double*)c->ts, (const double*)c->tgt,
-                             base, sd.n_pad, pts / 16, (double)lbx, (double)lbt, (double)sx, (double)st, (double)c->nu,
-                             (vec4<double>*)c->O, (double*)c->part, c->R, ci > 0 ? 1 : 0, c->t16_bsync, c->t16_bcount, n_bg,
-                             c->t16_gscr);
-          HIPCHK(hipGetLastError());
+          int rc = PINN_EINVAL;
+          switch (c->nd.n_hidden) {            // the stash is a register array: the depth is a template parameter
+            case 2: rc = t16_fused_launch<PDE, 2>(c, sd, base, pts, ci, wgs, n_bg, lbx, lbt, sx, st); break;
+            case 3: rc = t16_fused_launch<PDE, 3>(c, sd, base, pts, ci, wgs, n_bg, lbx, lbt, sx, st); break;
+            case 4: rc = t16_fused_launch<PDE, 4>(c, sd, base, pts, ci, wgs, n_bg, lbx, lbt, sx, st); break;
+          }
+          if (rc) return rc;
           continue;
         }
       }
@@ -1836,8 +1848,8 @@ int pinn_sync(pinn_ctx* c) {
 int pinn_set_kernel_path(pinn_ctx* c, int path) {
   REQUIRE(c && path >= 0 && path <= 8, "path must be 0 (generic), 1 (fused width-20), 2 (fused width-20, register stash), "
           "3 (wide MFMA sweeps), 4 (shape-generic MFMA sweeps), 5 / 6 (4's forward / reverse half with the generic other half), "
-          "7 (fused width-20 float64, register stash), 8 (fused float64 MFMA sweep, widths 65..128, 4 hidden layers)");
-  if (path == 8) REQUIRE(t16_fused_ok(c), "the fused float64 sweep needs float64, hidden width 65..128 and 4 hidden layers");
+          "7 (fused width-20 float64, register stash), 8 (fused float64 MFMA sweep, widths 65..128, 2-4 hidden layers)");
+  if (path == 8) REQUIRE(t16_fused_ok(c), "the fused float64 sweep needs float64, hidden width 65..128 and 2, 3 or 4 hidden layers");
   if (path >= 4 && path <= 6) REQUIRE(tile16_ok(c), "the shape-generic MFMA sweeps need hidden width <= 128");
   if (path == 7)
     REQUIRE(fused_f64_ok(c), "the float64 register-stash path needs float64, hidden width 20, 4, 6 or 8 hidden layers and a Burgers problem");

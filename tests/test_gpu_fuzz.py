@@ -21,6 +21,7 @@ def cases():
     out = []
     fixed = [("burgers", 20, 8), ("burgers_ide", 20, 8), ("burgers", 20, 3), ("schrodinger", 100, 4),
              ("burgers", 100, 4), ("burgers_ide", 65, 4), ("schrodinger", 128, 4),      # the fused float64 sweep (path 8)
+             ("schrodinger", 100, 2), ("burgers", 80, 3), ("burgers_ide", 112, 2),
              ("burgers", 1, 1), ("burgers", 128, 2), ("schrodinger", 24, 3), ("burgers_ide", 7, 11)]
     for pde, W, H in fixed:
         out.append((pde, W, H, int(rs.randint(1, 700)), int(rs.randint(1, 90)), int(rs.randint(0, 2 ** 31))))
