@@ -143,6 +143,13 @@ def test_c_abi_exports_every_declared_symbol():
     # plain C types only in the header
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
     assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
+    # ... and the header is valid ISO C on its own (what a cgo / ctypes / JNI binding generator would be fed)
+    import shutil
+    import subprocess
+    if shutil.which("gcc"):
+        res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                              os.path.join(ROOT, "include", "pinn_hip.h")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
 
 
 def test_library_staleness_is_decided_by_source_contents_not_file_times(monkeypatch):
