@@ -203,7 +203,11 @@ def test_bench_two_ranks_on_one_device_end_to_end(tmp_path):
     port = 29300 + os.getpid() % 90
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "3"]
+           "--warmup", "3", "--no-cfg34-legs"]
+    # (--no-cfg34-legs: with BOTH ranks on one device the Schrodinger leg can deadlock until the mailbox times out -- the
+    #  polling reduction workgroups of the rank that is an evaluation ahead hold 16 KB of LDS on every CU and the other
+    #  rank's 157 KB sweep cannot be placed; a hazard of sharing a GPU, not of the N-GPU launch.  The legs' sharding is
+    #  covered by tests/test_data_parallel_gloo.py and, on width 64, tests/test_gpu_dp_scripts.py)
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert res.returncode == 0 and len(lines) == 1, res.stdout[-3000:] + res.stderr[-3000:]
