@@ -53,7 +53,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   using V4 = vec4<double>;
   static_assert(H >= 2, "at least one hidden-to-hidden layer");
   constexpr int NT = 8, NWV = 8, WP = GEO::WP, PD = GEO::PD, RP = 4 * NWV, THREADS = 64 * NWV;
-  constexpr int NI = WP / RP, KS = 2 * NWV, NKO = WP / KS, DEPTH = T16_DEPTH;
+  constexpr int NI = WP / RP, KS = 2 * NWV, NKO = WP / KS;
   (void)NT;
   extern __shared__ __attribute__((aligned(16))) char t16_smem[];
   V4* const T0 = reinterpret_cast<V4*>(t16_smem);
@@ -100,39 +100,61 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     const real w0 = th[nd.off_w[0] + j], w1 = th[nd.off_w[0] + W + j], b0 = th[nd.off_b[0] + j];
     return V4{tanh_mm(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
   };
-  // one layer GEMM of this wave's feature tile: acc_c[r] = sum_k A(row, k) B_c[k][point m], weights straight from L2
-  // with DEPTH chunks of four k-steps in flight (k_t16_fwd / k_t16_bwd, WLDS == false).  TRANSPOSED: A(row, k) =
-  // Wm[row * W + k] (adjoint GEMM), else Wm[k * W + row] (forward GEMM)
+  // one layer GEMM of this wave's feature tile: acc_c[r] = sum_k A(row, k) B_c[k][point m], weights straight from L2.
+  // TRANSPOSED: A(row, k) = Wm[row * W + k] (adjoint GEMM), else Wm[k * W + row] (forward GEMM).
+  // Shape of the loop (round 4; the generic sweeps keep theirs):
+  //  * k-steps whose four rows k = 4 s + g all exist (s < W / 4) run UNGUARDED in chunks of four: plain loads (a padded
+  //    output row ra >= W reads row W - 1; its results are discarded), two chunks of weights in flight; the guards of
+  //    k_t16_fwd made every load a predicated branch (8 instructions) and every k-step its own basic block;
+  //  * the B operands of k-step s + 1 are requested from LDS BEFORE the matrix instructions of k-step s
+  //    (sched_barrier pins it): as generated before, every k-step waited for its own ds_read;
+  //  * at most three unguarded and one guarded (W % 4 != 0) k-step remain for the tail.
   auto gemm = [&](const real* __restrict__ Wm, const V4* __restrict__ Bt, auto tr_tag, acc_t& a0, acc_t& a1,
                   acc_t& a2, acc_t& a3) {
     constexpr bool transposed = decltype(tr_tag)::value;
-    const int ra = 16 * wave + m;
-    real wq[DEPTH + 1][4];
-    auto fetch = [&](int c, real (&dst)[4]) {
+    const int ra = 16 * wave + m, rac = ra < W ? ra : W - 1;
+    const int off0 = transposed ? rac * W + g : g * W + rac;      // element of k-step 0
+    const int kstr = transposed ? 4 : 4 * W;                      // elements per k-step
+    const int kfull = W >> 2, nfc = kfull >> 2;                   // unguarded k-steps; full chunks of four of them
+    const real* __restrict__ wp = Wm + off0;
+    const V4* __restrict__ bp = Bt + g * PD + m;                  // B rows 4 s + g, point m: + 4 PD per k-step
+    auto fetch = [&](int c, real (&dst)[4]) {                     // chunk c (clamped: a fetch beyond the last chunk re-reads it)
+      const int cc = c < nfc ? c : (nfc > 0 ? nfc - 1 : 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = wp[(4 * cc + u) * kstr];
+    };
+    // three weight buffers used in rotation (the loop is unrolled by three: no register copies, and the wait before a
+    // chunk is for loads issued TWO chunks earlier)
+    real w0[4], w1[4], w2[4];
+    if (nfc > 0) { fetch(0, w0); fetch(1, w1); }
+    V4 bc = bp[0];
+    auto chunk = [&](const int c, real (&cur)[4], real (&fill)[4]) {
+      fetch(c + 2, fill);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int k = 4 * (4 * c + u) + g;
-        dst[u] = (k < W && ra < W) ? (transposed ? Wm[ra * W + k] : Wm[k * W + ra]) : real(0);
+        const V4 bn = bp[(4 * c + u + 1) * 4 * PD];               // next k-step's rows (< WP: always inside the tile)
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = t16_mfma<real, acc_t>(cur[u], bc.x, a0);
+        a1 = t16_mfma<real, acc_t>(cur[u], bc.y, a1);
+        a2 = t16_mfma<real, acc_t>(cur[u], bc.z, a2);
+        a3 = t16_mfma<real, acc_t>(cur[u], bc.w, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        bc = bn;
       }
     };
-#pragma unroll
-    for (int q = 0; q < DEPTH; ++q) fetch(q, wq[q]);
-    for (int c = 0; c < nchunks; ++c) {
-      fetch(c + DEPTH, wq[DEPTH]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (4 * c + u >= ksteps) break;                           // last chunk: only the k-steps that exist (uniform)
-        const V4 b = Bt[(4 * (4 * c + u) + g) * PD + m];
-        a0 = t16_mfma<real, acc_t>(wq[0][u], b.x, a0);
-        a1 = t16_mfma<real, acc_t>(wq[0][u], b.y, a1);
-        a2 = t16_mfma<real, acc_t>(wq[0][u], b.z, a2);
-        a3 = t16_mfma<real, acc_t>(wq[0][u], b.w, a3);
-      }
-#pragma unroll
-      for (int q = 0; q < DEPTH; ++q) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wq[q][u] = wq[q + 1][u];
-      }
+    for (int c = 0; c < nfc; c += 3) {
+      chunk(c, w0, w2);
+      if (c + 1 < nfc) chunk(c + 1, w1, w0);
+      if (c + 2 < nfc) chunk(c + 2, w2, w1);
+    }
+    for (int ks = 4 * nfc; ks < ksteps; ++ks) {                   // tail: <= 3 unguarded k-steps + one guarded
+      const int k = 4 * ks + g;
+      const real a = k < W ? wp[(k < W ? ks : 0) * kstr] : real(0);
+      const V4 b = bp[ks * 4 * PD];
+      a0 = t16_mfma<real, acc_t>(a, b.x, a0);
+      a1 = t16_mfma<real, acc_t>(a, b.y, a1);
+      a2 = t16_mfma<real, acc_t>(a, b.z, a2);
+      a3 = t16_mfma<real, acc_t>(a, b.w, a3);
     }
   };
 
@@ -309,15 +331,25 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       for (int tau = t_lo; tau < t_hi; ++tau) {
         const int rt = tau / ntl, ct = tau - rt * ntl;
         const V4 nxt = fetch_old(tau + 1);
-        acc_t acc = {0, 0, 0, 0};
+        // two accumulator chains (even / odd quarter of the 16 points) instead of one 16-deep dependent chain, and the
+        // operands of quarter s4 + 1 requested before the matrix instructions of quarter s4
+        acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+        const V4* __restrict__ ap = TI + (16 * rt + m) * PD + g;
+        const V4* __restrict__ bq = Bcur + (16 * ct + m) * PD + g;
+        V4 A = ap[0], B = bq[0];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
+          const V4 An = ap[s4 < 3 ? 4 * (s4 + 1) : 0], Bn = bq[s4 < 3 ? 4 * (s4 + 1) : 0];
+          __builtin_amdgcn_sched_barrier(0);
           acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
-          acc = t16_mfma<real, acc_t>(A.y, B.y, acc);
+          acc2 = t16_mfma<real, acc_t>(A.y, B.y, acc2);
           acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
-          acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
+          acc2 = t16_mfma<real, acc_t>(A.w, B.w, acc2);
+          __builtin_amdgcn_sched_barrier(0);
+          A = An; B = Bn;
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #if T16_ABL == 3
         if (acc[0] == real(-1.2345e300)) gsd[(size_t)tau * 64] = V4{acc[0], acc[1], acc[2], acc[3]};
 #else
