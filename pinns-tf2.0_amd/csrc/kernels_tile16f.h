@@ -109,6 +109,9 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   //  * the B operands of k-step s + 1 are requested from LDS BEFORE the matrix instructions of k-step s
   //    (sched_barrier pins it): as generated before, every k-step waited for its own ds_read;
   //  * at most three unguarded and one guarded (W % 4 != 0) k-step remain for the tail.
+  // (Tried and dropped: requesting a GEMM's first two weight chunks ahead of the phase before it -- the previous layer's
+  //  tanh epilogue, the gradient tiles -- so that no GEMM starts with a cold L2 round trip: 256 VGPRs instead of 238
+  //  and 449 vs 446 us per step, same box: with two waves per SIMD the other wave already covers that latency.)
   auto gemm = [&](const real* __restrict__ Wm, const V4* __restrict__ Bt, auto tr_tag, acc_t& a0, acc_t& a1,
                   acc_t& a2, acc_t& a3) {
     constexpr bool transposed = decltype(tr_tag)::value;
