@@ -162,6 +162,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   };
 
     // =========================================================================================== forward sweep
+    real a0e[NI];                             // layer 0's tanh values of this thread's (feature, point) items: the reverse
+                                              // sweep needs them twice more (a tanh is ~45 instructions; k_t16_bwd reads S)
     {  // dense 0: items (feature j, point pe), point fastest
       const real x = xs[base + lp0 + pe], t = ts[base + lp0 + pe];
       const real hx = sx * (x - lbx) - real(1), ht = st * (t - lbt) - real(1);
@@ -170,9 +172,12 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       for (int i = 0; i < NI; ++i) {
         const int j = (tid >> 4) + RP * i;
         V4 c{0, 0, 0, 0};
+        a0e[i] = real(0);
         if (j < W) {
           real d1, d2;
-          c = channels_of(dense0(j, hx, ht), d1, d2);
+          const V4 s0 = dense0(j, hx, ht);
+          a0e[i] = s0.x;
+          c = channels_of(s0, d1, d2);
         }
         T0[j * PD + pe] = c;
       }
@@ -378,7 +383,10 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           const int k = 16 * wave + TR::out_row(lane, r);
           V4 v{0, 0, 0, 0};
           if (tile_live && k < W) {
-            const V4 sk = d >= 2 ? stash[d >= 2 ? d - 2 : 0][r] : dense0(k, hxy[m], hxy[16 + m]);
+            // layer 0 (d == 1): TI holds its OUTPUT channels, whose first is the tanh value -- this lane's own element,
+            // read before it is overwritten below; the other three stash entries are weight constants
+            const V4 sk = d >= 2 ? stash[d >= 2 ? d - 2 : 0][r]
+                                 : V4{TI[k * PD + m].x, sx * th[nd.off_w[0] + k], st * th[nd.off_w[0] + W + k], real(0)};
             v = preact_adjoint(sk, V4{a0[r], a1[r], a2[r], a3[r]});
           }
           Bnxt[k * PD + m] = v;
@@ -394,14 +402,13 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
             Bcur[j * PD + m] = c;
           }
         } else {                              // ... layer 0: recomputed, items (feature j, point pe)
-          const real hx = hxy[pe], ht = hxy[16 + pe];
 #pragma unroll
           for (int i = 0; i < NI; ++i) {
             const int j = (tid >> 4) + RP * i;
             V4 c{0, 0, 0, 0};
             if (j < W) {
               real d1, d2;
-              c = channels_of(dense0(j, hx, ht), d1, d2);
+              c = channels_of(V4{a0e[i], sx * th[nd.off_w[0] + j], st * th[nd.off_w[0] + W + j], real(0)}, d1, d2);
             }
             Bcur[j * PD + pe] = c;
           }
