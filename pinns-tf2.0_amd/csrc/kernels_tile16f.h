@@ -34,8 +34,12 @@
 
 namespace pinn {
 
-inline size_t t16_fused_lds() {
-  return (size_t)(2 * T16Geo<8>::TILE * 4 + 2 * 8 * 2 * 16 * 4 + 2 * 16 * 4 + 32 + 7 * 16) * sizeof(double);
+// dynamic LDS of the kernel; t16_fused_small_in_lds: the per-feature gradients of the biases and of layer 0 ((H + 2) W
+// doubles) fit behind the fixed areas and are accumulated there over the groups instead of in the row
+inline size_t t16_fused_fixed_doubles() { return (size_t)2 * T16Geo<8>::TILE * 4 + 2 * 8 * 2 * 16 * 4 + 2 * 16 * 4 + 32 + 7 * 16; }
+inline bool t16_fused_small_in_lds(int W, int H) { return (t16_fused_fixed_doubles() + (size_t)(H + 2) * W) * sizeof(double) <= 160 * 1024; }
+inline size_t t16_fused_lds(int W, int H) {
+  return (t16_fused_fixed_doubles() + (t16_fused_small_in_lds(W, H) ? (size_t)(H + 2) * W : 0)) * sizeof(double);
 }
 
 template <int PDE, int H>
@@ -63,6 +67,13 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   real* const hxy = reinterpret_cast<real*>(seeds + 32);          // [2][16] normalised inputs
   real* const lsum = hxy + 32;                                    // [7][16] per-point-slot sums over the groups: loss parts (3),
                                                                   // lambda gradients (2), output-bias gradients (2)
+  // Small gradients accumulated ON CHIP over the workgroup's groups and added into the row once: read-modify-writes of
+  // the row per group are dependent global round trips (~1.5 k cycles each, a dozen per group on the critical path).
+  //   gsm[(H + 2) W] (LDS, when it fits: t16_fused_small_in_lds): bias gradients of layers 1..H-1, then layer 0's
+  //   (d/dW_x, d/dW_t, d/db) per feature;  gwacc (registers): output-layer weight gradients, per lane, summed over the
+  //   16 points of a DPP row at the end
+  real* const gsm = lsum + 7 * 16;
+  const bool small_lds = (size_t)((char*)(gsm + (H + 2) * nd.width) - t16_smem) <= (size_t)160 * 1024;
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int W = nd.width, NO = nd.n_out;
   const int ksteps = (W + 3) / 4, nchunks = (ksteps + 3) >> 2;
@@ -84,6 +95,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     __syncthreads();                          // (global stores of one workgroup, read back by the same workgroup)
   }
   if (tid0 < 7 * 16) lsum[tid0] = real(0);    // (published by the first barrier of the group loop)
+  if (small_lds) for (int i = tid0; i < (H + 2) * nd.width; i += THREADS) gsm[i] = real(0);
+  real gwacc[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
 
   // (k_t16_fwd keeps dense 0's parameters and the output layer's k-slice in registers across groups: 40 registers
   //  this kernel needs for the stash -- they are re-read from L2 per group instead)
@@ -299,12 +312,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           gw0 = dot4(in, s0);
           gw1 = dot4(in, s1);
         }
-        gw0 = sum16(gw0);
-        gw1 = sum16(gw1);
-        if (m == 0 && j < W) {
-          row[nd.off_w[H] + j * NO] += gw0;
-          if (NO > 1) row[nd.off_w[H] + j * NO + 1] += gw1;
-        }
+        gwacc[r][0] += gw0;
+        gwacc[r][1] += gw1;
         Bcur[j * PD + m] = zb;
       }
     }
@@ -368,7 +377,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       if (tid < W) {                          // bias gradient of layer d
         real sb_ = 0;
         for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
-        row[nd.off_b[d] + tid] += sb_;
+        if (small_lds) gsm[(d - 1) * W + tid] += sb_;
+        else row[nd.off_b[d] + tid] += sb_;
       }
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p] into registers -- no barrier between the
       // gradient tiles and this GEMM (both only READ the two tiles), so the waves of a SIMD drift apart and one's
@@ -425,11 +435,34 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         gt += hxy[16 + p] * zb.x + st * zb.z;
         gb += zb.x;
       }
-      row[nd.off_w[0] + tid] += gx;
-      row[nd.off_w[0] + W + tid] += gt;
-      row[nd.off_b[0] + tid] += gb;
+      if (small_lds) {
+        gsm[(H - 1) * W + tid] += gx; gsm[H * W + tid] += gt; gsm[(H + 1) * W + tid] += gb;
+      } else {
+        row[nd.off_w[0] + tid] += gx;
+        row[nd.off_w[0] + W + tid] += gt;
+        row[nd.off_b[0] + tid] += gb;
+      }
     }
     __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group
+  }
+  {  // the on-chip sums -> the partial row
+    const int lane = tid0 & 63, m = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {             // output-layer weights: this lane's rows, summed over the 16 points
+      const int j = 16 * wave + TR::out_row(lane, r);
+      const real g0 = sum16(gwacc[r][0]), g1 = sum16(gwacc[r][1]);
+      if (m == 0 && j < W) {
+        row[nd.off_w[H] + j * NO] += g0;
+        if (NO > 1) row[nd.off_w[H] + j * NO + 1] += g1;
+      }
+    }
+    if (small_lds && tid0 < W) {              // (same thread accumulated and reads: no barrier needed)
+#pragma unroll
+      for (int d = 1; d < H; ++d) row[nd.off_b[d] + tid0] += gsm[(d - 1) * W + tid0];
+      row[nd.off_w[0] + tid0] += gsm[(H - 1) * W + tid0];
+      row[nd.off_w[0] + W + tid0] += gsm[H * W + tid0];
+      row[nd.off_b[0] + tid0] += gsm[(H + 1) * W + tid0];
+    }
   }
   {  // tile-major scratch -> the partial row (every entry written by the lane that owns it: no barrier needed)
     const int lane = tid0 & 63, m = lane & 15;
