@@ -132,11 +132,26 @@ __device__ __forceinline__ int point_class(const SetDesc& sd, int g) {
 // Per-point loss contributions and output adjoints.
 //   sb[o] <- (h_bar, p_bar, q_bar, r_bar) of output o;  lt[0..2] <- (f, data, boundary) loss parts
 //   dl[0..1] <- d/d lambda_1, d/d lambda_2 contributions (identification only)
+// point_seeds_own: the same with the point's OWN outputs handed in (ou, and ov for two-output nets) instead of read from
+// O -- a fused kernel has them on chip; O is read only for the partner of a periodic-boundary pair
+template <typename real, int PDE>
+__device__ __forceinline__ void point_seeds_own(const SetDesc& sd, int g, int n_pad, const vec4<real>& ou,
+                                                const vec4<real>& ov, const vec4<real>* __restrict__ O,
+                                                const real* __restrict__ tgt, real c1, real c2,
+                                                vec4<real> sb[2], real lt[3], real dl[2]);
 template <typename real, int PDE>
 __device__ __forceinline__ void point_seeds(const SetDesc& sd, int g, int n_pad,
                                             const vec4<real>* __restrict__ O,
                                             const real* __restrict__ tgt, real c1, real c2,
                                             vec4<real> sb[2], real lt[3], real dl[2]) {
+  const vec4<real> ou = O[g], ov = PDE == 2 ? O[(size_t)n_pad + g] : vec4<real>{0, 0, 0, 0};
+  point_seeds_own<real, PDE>(sd, g, n_pad, ou, ov, O, tgt, c1, c2, sb, lt, dl);
+}
+template <typename real, int PDE>
+__device__ __forceinline__ void point_seeds_own(const SetDesc& sd, int g, int n_pad, const vec4<real>& ou,
+                                                const vec4<real>& ov, const vec4<real>* __restrict__ O,
+                                                const real* __restrict__ tgt, real c1, real c2,
+                                                vec4<real> sb[2], real lt[3], real dl[2]) {
   const int cls = point_class(sd, g);
   sb[0] = sb[1] = vec4<real>{0, 0, 0, 0};
   lt[0] = lt[1] = lt[2] = real(0);
@@ -144,7 +159,7 @@ __device__ __forceinline__ void point_seeds(const SetDesc& sd, int g, int n_pad,
   if (cls == CLS_PAD) return;
   const real inv_nf = (real)sd.inv_nf, inv_nu = (real)sd.inv_nu, inv_nb = (real)sd.inv_nb;
   if (PDE == 0 || PDE == 1) {   // Burgers (inference / identification)
-    const vec4<real> o = O[g];
+    const vec4<real> o = ou;
     const bool res = (PDE == 0) ? (cls == CLS_COL) : (cls == CLS_DATA);
     if (res) {
       const real f = o.z + c1 * o.x * o.y - c2 * o.w;       // u_t + c1 u u_x - c2 u_xx
@@ -159,7 +174,6 @@ __device__ __forceinline__ void point_seeds(const SetDesc& sd, int g, int n_pad,
       sb[0].x += real(2) * dd * inv_nu;
     }
   } else {                      // Schrodinger
-    const vec4<real> ou = O[g], ov = O[(size_t)n_pad + g];
     if (cls == CLS_COL) {
       const real u = ou.x, v = ov.x, h2 = u * u + v * v;
       const real fu = ou.z + real(0.5) * ov.w + h2 * v;     // u_t + v_xx/2 + |h|^2 v
@@ -176,7 +190,9 @@ __device__ __forceinline__ void point_seeds(const SetDesc& sd, int g, int n_pad,
       sb[0].x = real(2) * du * inv_nu; sb[1].x = real(2) * dv * inv_nu;
     } else {                    // periodic boundary pair (g in lo  <->  g + n_b in hi)
       const int lo = (cls == CLS_BLO) ? g : g - sd.n_b, hi = lo + sd.n_b;
-      const vec4<real> ul = O[lo], uh = O[hi], vl = O[(size_t)n_pad + lo], vh = O[(size_t)n_pad + hi];
+      const bool is_lo = cls == CLS_BLO;
+      const vec4<real> ul = is_lo ? ou : O[lo], uh = is_lo ? O[hi] : ou;
+      const vec4<real> vl = is_lo ? ov : O[(size_t)n_pad + lo], vh = is_lo ? O[(size_t)n_pad + hi] : ov;
       const real dhu = ul.x - uh.x, dhv = vl.x - vh.x, dpu = ul.y - uh.y, dpv = vl.y - vh.y;
       const real sg = (cls == CLS_BLO) ? real(2) * inv_nb : real(-2) * inv_nb;
       if (cls == CLS_BLO) lt[2] = (dhu * dhu + dhv * dhv + dpu * dpu + dpv * dpv) * inv_nb;

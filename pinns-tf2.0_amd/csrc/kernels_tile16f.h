@@ -253,7 +253,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
         }
         tot.x += th[nd.off_b[H] + o];
-        O[(size_t)o * n_pad + base + lp0 + pe] = tot;
+        O[(size_t)o * n_pad + base + lp0 + pe] = tot;            // (for the partner of a boundary pair, and pinn_predict's callers)
+        seeds[o * 16 + pe] = tot;                                 // the group's own outputs stay on chip for the seeds
       }
     }
     if (grp < n_bgroups) {
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       const int pt = base + lp0 + tid;
       V4 sb[2];
       real lt[3], dl[2];
-      point_seeds<real, PDE>(sd, pt, n_pad, O, tgt, c1, c2, sb, lt, dl);
+      const V4 ou = seeds[tid], ov = NO > 1 ? seeds[16 + tid] : V4{0, 0, 0, 0};   // (read before this thread overwrites them)
+      point_seeds_own<real, PDE>(sd, pt, n_pad, ou, ov, O, tgt, c1, c2, sb, lt, dl);
       seeds[tid] = sb[0]; seeds[16 + tid] = sb[1];
       lsum[tid] += lt[0]; lsum[16 + tid] += lt[1]; lsum[32 + tid] += lt[2];
       lsum[48 + tid] += dl[0]; lsum[64 + tid] += dl[1];
