@@ -390,7 +390,7 @@ static int ensure_sets(pinn_ctx* c) {
 #endif
   const int wide_wg = (c->chunk / 16 < c->n_cu) ? c->chunk / 16 : c->n_cu;     // persistent workgroups (path 3)
   const size_t rows = t16_bwd_on(c) ? (size_t)t16_wgs(c, c->chunk) : c->path == 3 ? (size_t)wide_wg : (c->path == 2 || c->path == 7) ? (size_t)c->n_wg : c->path == 1 ? (size_t)n_pad / 64 : (size_t)c->n_rows;
-  const bool no_stash = c->path == 2 || c->path == 7;
+  const bool no_stash = c->path == 2 || c->path == 7 || c->path == 8;   // (path 8: 257 MB at cfg 4 that nothing would touch)
   const size_t need_S = no_stash ? 16 : H * W * stash_pts * 4 * rs;
   const size_t need_Z = no_stash ? 16 : W * (size_t)c->chunk * 4 * rs;
   const size_t need_part = rows * c->R * rs;
@@ -578,6 +578,8 @@ static int launch_sweeps(pinn_ctx* c, hipEvent_t* ev4, const AdamFuse* af) {
           // the outputs over itself (kernels_tile16f.h); otherwise a forward sweep over those groups runs first
           int n_bg = (PDE == 2 && base == 0 && sd.n_b > 0) ? (2 * sd.n_b + 15) / 16 : 0;
           if (n_bg > wgs) {
+            const size_t need_S = (size_t)c->nd.n_hidden * c->nd.width * (size_t)c->chunk * 4 * sizeof(double);   // (k_t16_fwd stashes)
+            if (need_S > c->cap_S) { if (dev_alloc(&c->S, need_S)) return PINN_EHIP; c->cap_S = need_S; }
             if (int rc = t16_fwd<real>(c, c->xs, c->ts, sd.n_pad, c->chunk, c->O, 0, 16 * n_bg < pts ? 16 * n_bg : pts, lbx, lbt, sx, st)) return rc;
             n_bg = 0;
           }
