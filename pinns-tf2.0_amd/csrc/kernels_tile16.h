@@ -97,6 +97,65 @@ __device__ __forceinline__ real sum16(real v) {        // sum over the 16 lanes 
   return v;
 }
 
+// One layer GEMM of a 16-row feature tile with the weights read straight from L2 (round 4; the eight-wave sweeps and
+// k_t16_fused):  acc_c[r] += sum_k A(row, k) B_c[k][point m],  A(row, k) = Wm[row * W + k] if TRANSPOSED (adjoint GEMM)
+// else Wm[k * W + row] (forward GEMM); `ra` = this lane's row (16 tile + m), B rows are vec4 (four Taylor channels).
+//  * k-steps whose four rows k = 4 s + g all exist (s < W / 4) run UNGUARDED in chunks of four: plain loads (a padded
+//    output row ra >= W reads row W - 1; its results are discarded by the caller), three weight buffers in rotation --
+//    the loop is unrolled by three, no register copies, and the wait before a chunk is for loads issued two chunks
+//    earlier.  (Guarded loads compile to a predicated branch each, 8 instructions, and make every k-step its own basic
+//    block whose ds_read is waited for right before its four matrix instructions.)
+//  * the B operands of k-step s + 1 are requested from LDS BEFORE the matrix instructions of k-step s (sched_barrier
+//    pins it);
+//  * at most three unguarded and one guarded (W % 4 != 0) k-step remain for the tail.
+template <typename real, bool TRANSPOSED, int PD, typename acc_t>
+__device__ __forceinline__ void t16_gemm_l2(const real* __restrict__ Wm, const vec4<real>* __restrict__ Bt, const int W,
+                                            const int ra, const int m, const int g, acc_t& a0, acc_t& a1, acc_t& a2,
+                                            acc_t& a3) {
+  using V4 = vec4<real>;
+  const int ksteps = (W + 3) >> 2, kfull = W >> 2, nfc = kfull >> 2;   // k-steps; unguarded ones; full chunks of four
+  const int rac = ra < W ? ra : W - 1;
+  const int kstr = TRANSPOSED ? 4 : 4 * W;                        // elements per k-step
+  const real* __restrict__ wp = Wm + (TRANSPOSED ? rac * W + g : g * W + rac);
+  const V4* __restrict__ bp = Bt + g * PD + m;                    // B rows 4 s + g, point m: + 4 PD per k-step
+  auto fetch = [&](int c, real (&dst)[4]) {                       // chunk c (clamped: a fetch beyond the last chunk re-reads it)
+    const int cc = c < nfc ? c : (nfc > 0 ? nfc - 1 : 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dst[u] = wp[(4 * cc + u) * kstr];
+  };
+  real w0[4], w1[4], w2[4];
+  if (nfc > 0) { fetch(0, w0); fetch(1, w1); }
+  V4 bc = bp[0];
+  auto chunk = [&](const int c, real (&cur)[4], real (&fill)[4]) {
+    fetch(c + 2, fill);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const V4 bn = bp[(4 * c + u + 1) * 4 * PD];                 // next k-step's rows (always inside the tile)
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = t16_mfma<real, acc_t>(cur[u], bc.x, a0);
+      a1 = t16_mfma<real, acc_t>(cur[u], bc.y, a1);
+      a2 = t16_mfma<real, acc_t>(cur[u], bc.z, a2);
+      a3 = t16_mfma<real, acc_t>(cur[u], bc.w, a3);
+      __builtin_amdgcn_sched_barrier(0);
+      bc = bn;
+    }
+  };
+  for (int c = 0; c < nfc; c += 3) {
+    chunk(c, w0, w2);
+    if (c + 1 < nfc) chunk(c + 1, w1, w0);
+    if (c + 2 < nfc) chunk(c + 2, w2, w1);
+  }
+  for (int ks = 4 * nfc; ks < ksteps; ++ks) {                     // tail: <= 3 unguarded k-steps + one guarded
+    const int k = 4 * ks + g;
+    const real a = k < W ? wp[(k < W ? ks : 0) * kstr] : real(0);
+    const V4 b = bp[ks * 4 * PD];
+    a0 = t16_mfma<real, acc_t>(a, b.x, a0);
+    a1 = t16_mfma<real, acc_t>(a, b.y, a1);
+    a2 = t16_mfma<real, acc_t>(a, b.z, a2);
+    a3 = t16_mfma<real, acc_t>(a, b.w, a3);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward sweep over points [base, base + 16 n_groups): fills S and O exactly as k_forward does
 // ---------------------------------------------------------------------------------------------------------
@@ -204,6 +263,8 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_fwd(NetDesc nd, const real* __
             a2 = t16_mfma<real, acc_t>(a, b.z, a2);
             a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
+        } else if constexpr (NWV == 8) {
+          t16_gemm_l2<real, false, PD, acc_t>(Wl, Tin, W, ja, m, g, a0, a1, a2, a3);
         } else {
           // weights straight from L2: the A operands of a chunk of four k-steps are fetched one chunk ahead, so their
           // latency (several hundred cycles) hides under the 16 matrix instructions of the chunk in flight instead
@@ -431,13 +492,35 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
           }
         }
         acc_t acc = {0, 0, 0, 0};
+        if constexpr (NWV == 8) {
+          // (round 4, as k_t16_fused) two accumulator chains instead of one 16-deep dependent chain, and the operands
+          // of quarter s4 + 1 requested from LDS before the matrix instructions of quarter s4
+          acc_t acc2 = {0, 0, 0, 0};
+          const V4* __restrict__ ap = TI + (16 * rt + m) * PD + g;
+          const V4* __restrict__ bq = Bcur + (16 * ct + m) * PD + g;
+          V4 A = ap[0], B = bq[0];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
-          acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
-          acc = t16_mfma<real, acc_t>(A.y, B.y, acc);
-          acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
-          acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const V4 An = ap[s4 < 3 ? 4 * (s4 + 1) : 0], Bn = bq[s4 < 3 ? 4 * (s4 + 1) : 0];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
+            acc2 = t16_mfma<real, acc_t>(A.y, B.y, acc2);
+            acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
+            acc2 = t16_mfma<real, acc_t>(A.w, B.w, acc2);
+            __builtin_amdgcn_sched_barrier(0);
+            A = An; B = Bn;
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            const V4 A = TI[(16 * rt + m) * PD + 4 * s4 + g], B = Bcur[(16 * ct + m) * PD + 4 * s4 + g];
+            acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
+            acc = t16_mfma<real, acc_t>(A.y, B.y, acc);
+            acc = t16_mfma<real, acc_t>(A.z, B.z, acc);
+            acc = t16_mfma<real, acc_t>(A.w, B.w, acc);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -494,6 +577,8 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
             a2 = t16_mfma<real, acc_t>(a, b.z, a2);
             a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
+        } else if constexpr (NWV == 8) {
+          t16_gemm_l2<real, true, PD, acc_t>(Wd, Bcur, W, k, m, g, a0, a1, a2, a3);
         } else {                              // weights from L2, fetched one chunk of four k-steps ahead (see k_t16_fwd)
           const int nchunks = (ksteps + 3) >> 2;
           constexpr int DEPTH = NWV == 8 ? T16_DEPTH : 1;

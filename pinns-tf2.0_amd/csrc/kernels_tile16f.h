@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   const bool small_lds = (size_t)((char*)(gsm + (H + 2) * nd.width) - t16_smem) <= (size_t)160 * 1024;
   const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int W = nd.width, NO = nd.n_out;
-  const int ksteps = (W + 3) / 4, nchunks = (ksteps + 3) >> 2;
+  const int ksteps = (W + 3) / 4;
   const bool tile_live = 16 * wave < W;                           // wave-uniform: this wave's feature tile has real rows
   real* __restrict__ row = part + (size_t)blockIdx.x * R;
   // Hidden-to-hidden weight gradients are accumulated over the workgroup's groups in a TILE-MAJOR scratch of its own
@@ -113,65 +113,15 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     const real w0 = th[nd.off_w[0] + j], w1 = th[nd.off_w[0] + W + j], b0 = th[nd.off_b[0] + j];
     return V4{tanh_mm(hx * w0 + ht * w1 + b0), sx * w0, st * w1, real(0)};
   };
-  // one layer GEMM of this wave's feature tile: acc_c[r] = sum_k A(row, k) B_c[k][point m], weights straight from L2.
-  // TRANSPOSED: A(row, k) = Wm[row * W + k] (adjoint GEMM), else Wm[k * W + row] (forward GEMM).
-  // Shape of the loop (round 4; the generic sweeps keep theirs):
-  //  * k-steps whose four rows k = 4 s + g all exist (s < W / 4) run UNGUARDED in chunks of four: plain loads (a padded
-  //    output row ra >= W reads row W - 1; its results are discarded), two chunks of weights in flight; the guards of
-  //    k_t16_fwd made every load a predicated branch (8 instructions) and every k-step its own basic block;
-  //  * the B operands of k-step s + 1 are requested from LDS BEFORE the matrix instructions of k-step s
-  //    (sched_barrier pins it): as generated before, every k-step waited for its own ds_read;
-  //  * at most three unguarded and one guarded (W % 4 != 0) k-step remain for the tail.
+  // one layer GEMM of this wave's feature tile: t16_gemm_l2 (kernels_tile16.h): unguarded chunks of four k-steps with
+  // plain, triple-buffered weight loads from L2, the next k-step's LDS operands requested before the current matrix
+  // instructions.
   // (Tried and dropped: requesting a GEMM's first two weight chunks ahead of the phase before it -- the previous layer's
   //  tanh epilogue, the gradient tiles -- so that no GEMM starts with a cold L2 round trip: 256 VGPRs instead of 238
   //  and 449 vs 446 us per step, same box: with two waves per SIMD the other wave already covers that latency.)
   auto gemm = [&](const real* __restrict__ Wm, const V4* __restrict__ Bt, auto tr_tag, acc_t& a0, acc_t& a1,
                   acc_t& a2, acc_t& a3) {
-    constexpr bool transposed = decltype(tr_tag)::value;
-    const int ra = 16 * wave + m, rac = ra < W ? ra : W - 1;
-    const int off0 = transposed ? rac * W + g : g * W + rac;      // element of k-step 0
-    const int kstr = transposed ? 4 : 4 * W;                      // elements per k-step
-    const int kfull = W >> 2, nfc = kfull >> 2;                   // unguarded k-steps; full chunks of four of them
-    const real* __restrict__ wp = Wm + off0;
-    const V4* __restrict__ bp = Bt + g * PD + m;                  // B rows 4 s + g, point m: + 4 PD per k-step
-    auto fetch = [&](int c, real (&dst)[4]) {                     // chunk c (clamped: a fetch beyond the last chunk re-reads it)
-      const int cc = c < nfc ? c : (nfc > 0 ? nfc - 1 : 0);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dst[u] = wp[(4 * cc + u) * kstr];
-    };
-    // three weight buffers used in rotation (the loop is unrolled by three: no register copies, and the wait before a
-    // chunk is for loads issued TWO chunks earlier)
-    real w0[4], w1[4], w2[4];
-    if (nfc > 0) { fetch(0, w0); fetch(1, w1); }
-    V4 bc = bp[0];
-    auto chunk = [&](const int c, real (&cur)[4], real (&fill)[4]) {
-      fetch(c + 2, fill);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const V4 bn = bp[(4 * c + u + 1) * 4 * PD];               // next k-step's rows (< WP: always inside the tile)
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = t16_mfma<real, acc_t>(cur[u], bc.x, a0);
-        a1 = t16_mfma<real, acc_t>(cur[u], bc.y, a1);
-        a2 = t16_mfma<real, acc_t>(cur[u], bc.z, a2);
-        a3 = t16_mfma<real, acc_t>(cur[u], bc.w, a3);
-        __builtin_amdgcn_sched_barrier(0);
-        bc = bn;
-      }
-    };
-    for (int c = 0; c < nfc; c += 3) {
-      chunk(c, w0, w2);
-      if (c + 1 < nfc) chunk(c + 1, w1, w0);
-      if (c + 2 < nfc) chunk(c + 2, w2, w1);
-    }
-    for (int ks = 4 * nfc; ks < ksteps; ++ks) {                   // tail: <= 3 unguarded k-steps + one guarded
-      const int k = 4 * ks + g;
-      const real a = k < W ? wp[(k < W ? ks : 0) * kstr] : real(0);
-      const V4 b = bp[ks * 4 * PD];
-      a0 = t16_mfma<real, acc_t>(a, b.x, a0);
-      a1 = t16_mfma<real, acc_t>(a, b.y, a1);
-      a2 = t16_mfma<real, acc_t>(a, b.z, a2);
-      a3 = t16_mfma<real, acc_t>(a, b.w, a3);
-    }
+    t16_gemm_l2<real, decltype(tr_tag)::value, PD, acc_t>(Wm, Bt, W, 16 * wave + m, m, g, a0, a1, a2, a3);
   };
 
     // =========================================================================================== forward sweep
