@@ -46,6 +46,11 @@ namespace pinn {
 #endif                         // layer's stash, ahead of the matrix instructions -- measured 8 us SLOWER on cfg 4 float64
                                // (605 vs 597 us, same box, profiles/r03_t16_ab.txt): with two waves per SIMD the other
                                // wave already covers those latencies and the extra live registers cost more
+#ifndef T16_GEMM4
+#define T16_GEMM4 1            // 1: the four-wave variants (widths <= 64) also use t16_gemm_l2 / the two-chain gradient tiles
+#endif                         // where their weights come from L2: same-box A/B (profiles/r04_t16_gemm4_ab.txt) 2x50^4x1 f64
+                               // 142.5 -> 130.5 us, f32 80.9 -> 74.5; 2x64^6x1 f64 241.8 -> 229.5; register counts keep
+                               // the launch plan's workgroups per CU (f32 forward 112 VGPRs: occupancy 3 -> 4)
 #ifndef T16_DEPTH
 #define T16_DEPTH 2            // eight-wave variants: chunks of four k-steps of L2-resident weights in flight ahead of the
                                // one in use (2 vs 1: 583 vs 605 us on cfg 4 float64, profiles/r03_t16_ab.txt); the
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_fwd(NetDesc nd, const real* __
             a2 = t16_mfma<real, acc_t>(a, b.z, a2);
             a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
-        } else if constexpr (NWV == 8) {
+        } else if constexpr (NWV == 8 || T16_GEMM4) {
           t16_gemm_l2<real, false, PD, acc_t>(Wl, Tin, W, ja, m, g, a0, a1, a2, a3);
         } else {
           // weights straight from L2: the A operands of a chunk of four k-steps are fetched one chunk ahead, so their
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
           }
         }
         acc_t acc = {0, 0, 0, 0};
-        if constexpr (NWV == 8) {
+        if constexpr (NWV == 8 || T16_GEMM4) {
           // (round 4, as k_t16_fused) two accumulator chains instead of one 16-deep dependent chain, and the operands
           // of quarter s4 + 1 requested from LDS before the matrix instructions of quarter s4
           acc_t acc2 = {0, 0, 0, 0};
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(64 * NWV) void k_t16_bwd(NetDesc nd, SetDesc sd, co
             a2 = t16_mfma<real, acc_t>(a, b.z, a2);
             a3 = t16_mfma<real, acc_t>(a, b.w, a3);
           }
-        } else if constexpr (NWV == 8) {
+        } else if constexpr (NWV == 8 || T16_GEMM4) {
           t16_gemm_l2<real, true, PD, acc_t>(Wd, Bcur, W, k, m, g, a0, a1, a2, a3);
         } else {                              // weights from L2, fetched one chunk of four k-steps ahead (see k_t16_fwd)
           const int nchunks = (ksteps + 3) >> 2;
