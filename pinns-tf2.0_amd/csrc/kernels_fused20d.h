@@ -42,6 +42,11 @@
 // 1: the tile loop re-reads the lane index through an opaque asm once per tile (what stopped the address hoisting of
 // k_wide_bwd / k_t16_fused).  Here it takes the tile-loop variants from 256 VGPRs + 6-11 AGPR spill slots to 238-242 / 0
 // and is 1 % SLOWER (same-box A/B, N_f = 10^6: 1991 / 2000 vs 1971 / 1978 us per Adam step): off.
+#ifndef PINN_PATTERN_AHEAD
+#define PINN_PATTERN_AHEAD 1     // weight patterns of the two GEMVs requested two steps ahead (0: hipcc's placement):
+                                 // same-box A/B 40.81 / 40.84 -> 40.57 / 40.50 us per Adam step at N_f = 10^4 -- the LDS
+                                 // latency in front of the matrix instructions was mostly covered already; kept
+#endif
 #ifndef PINN_OPAQUE_TILE_D
 #define PINN_OPAQUE_TILE_D 0
 #endif
@@ -277,6 +282,25 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         acc[0][n] = wl[nd.off_b[d] + 4 * n + s];
         acc[1][n] = acc[2][n] = acc[3][n] = 0.0;
       }
+      // The 25 weight patterns of the layer are requested from LDS TWO steps ahead of the four matrix instructions that
+      // consume them (sched_barrier pins the order).  Left to itself hipcc sinks every ds_read next to its consumer --
+      // `ds_read2_b64; s_waitcnt lgkmcnt(0); v_mfma` 259 times per tile (round-4 ISA count) -- and a lone wave then
+      // sits out the LDS latency in front of each group of matrix instructions.
+#if PINN_PATTERN_AHEAD
+      {
+        double Aq[2] = {wd[0], wd[80]};
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const int n = t / 5, m = t - 5 * n;
+          const double A = Aq[t & 1];
+          if (t + 2 < 25) Aq[t & 1] = wd[80 * ((t + 2) % 5) + 4 * ((t + 2) / 5)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#else
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
 #pragma unroll
@@ -286,6 +310,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
         }
       }
+#endif
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         const double a = tanh_d(acc[0][n]);
@@ -377,6 +402,21 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       for (int m = 0; m < 5; ++m) {
         ob[0][m] = ob[1][m] = ob[2][m] = ob[3][m] = 0.0;
       }
+#if PINN_PATTERN_AHEAD
+      {
+        double Aq[2] = {wd[0], wd[4]};
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const int m = t / 5, n = t - 5 * m;
+          const double A = Aq[t & 1];
+          if (t + 2 < 25) Aq[t & 1] = wd[80 * ((t + 2) / 5) + 4 * ((t + 2) % 5)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#else
 #pragma unroll
       for (int m = 0; m < 5; ++m) {
 #pragma unroll
@@ -386,6 +426,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
         }
       }
+#endif
       // dW_d[4m + i][4n + j]: the A operands are the layer-(d-1) output channels, rotated -- produced one in-group
       // ahead of the matrix instructions that consume them (20 values live instead of 40: the kernel sits at the
       // 256-VGPR limit, and with all of them live hipcc sank the accumulator fetches next to their uses)
