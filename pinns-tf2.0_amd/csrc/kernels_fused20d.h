@@ -45,7 +45,9 @@
 #ifndef PINN_PATTERN_AHEAD
 #define PINN_PATTERN_AHEAD 1     // weight patterns of the two GEMVs requested two steps ahead (0: hipcc's placement):
                                  // same-box A/B 40.81 / 40.84 -> 40.57 / 40.50 us per Adam step at N_f = 10^4 -- the LDS
-                                 // latency in front of the matrix instructions was mostly covered already; kept
+                                 // latency in front of the matrix instructions was mostly covered already; kept for the
+                                 // one-tile variants only: the tile-loop variants sit at 256 VGPRs and got 1.6 % SLOWER
+                                 // (rocprofv3, N_f = 10^6: 1968 -> 2000 us)
 #endif
 #ifndef PINN_OPAQUE_TILE_D
 #define PINN_OPAQUE_TILE_D 0
@@ -286,8 +288,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       // consume them (sched_barrier pins the order).  Left to itself hipcc sinks every ds_read next to its consumer --
       // `ds_read2_b64; s_waitcnt lgkmcnt(0); v_mfma` 259 times per tile (round-4 ISA count) -- and a lone wave then
       // sits out the LDS latency in front of each group of matrix instructions.
-#if PINN_PATTERN_AHEAD
-      {
+      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
         double Aq[2] = {wd[0], wd[80]};
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
@@ -299,18 +300,17 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-#else
+      } else {
 #pragma unroll
-      for (int n = 0; n < 5; ++n) {
+        for (int n = 0; n < 5; ++n) {
 #pragma unroll
-        for (int m = 0; m < 5; ++m) {
-          const double A = wd[80 * m + 4 * n];
+          for (int m = 0; m < 5; ++m) {
+            const double A = wd[80 * m + 4 * n];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
+            for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
+          }
         }
       }
-#endif
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         const double a = tanh_d(acc[0][n]);
@@ -402,8 +402,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       for (int m = 0; m < 5; ++m) {
         ob[0][m] = ob[1][m] = ob[2][m] = ob[3][m] = 0.0;
       }
-#if PINN_PATTERN_AHEAD
-      {
+      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
         double Aq[2] = {wd[0], wd[4]};
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
@@ -415,18 +414,17 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
-#else
+      } else {
 #pragma unroll
-      for (int m = 0; m < 5; ++m) {
+        for (int m = 0; m < 5; ++m) {
 #pragma unroll
-        for (int n = 0; n < 5; ++n) {
-          const double A = wd[80 * m + 4 * n];
+          for (int n = 0; n < 5; ++n) {
+            const double A = wd[80 * m + 4 * n];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
+            for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
+          }
         }
       }
-#endif
       // dW_d[4m + i][4n + j]: the A operands are the layer-(d-1) output channels, rotated -- produced one in-group
       // ahead of the matrix instructions that consume them (20 values live instead of 40: the kernel sits at the
       // 256-VGPR limit, and with all of them live hipcc sank the accumulator fetches next to their uses)
