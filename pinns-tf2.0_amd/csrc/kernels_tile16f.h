@@ -213,15 +213,19 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       // checked by the host), so those workgroups are co-resident and reach this point without waiting for anybody:
       // publish (fence + counter), wait until all n_bgroups groups of this launch are published (the counter is
       // never reset: btarget = its value after this launch), then drop this CU's L1 so the partners' outputs are
-      // read from L2.  Bounded: a lost partner costs a fraction of a second and wrong seeds, never a hang.
+      // read from L2.  Bounded: a lost partner costs a fraction of a second and a NaN loss (reported), never a hang.
       __threadfence();
       __syncthreads();
       if (tid == 0) {
         atomicAdd(bsync, 1u);
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-          if ((int)(__hip_atomic_load(bsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - btarget) >= 0) break;
-          __builtin_amdgcn_s_sleep(4);
+        bool arrived = false;
+        for (int spin = 0; spin < (1 << 22) && !arrived; ++spin) {
+          arrived = (int)(__hip_atomic_load(bsync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - btarget) >= 0;
+          if (!arrived) __builtin_amdgcn_s_sleep(4);
         }
+        // a partner that never published (its workgroup was not resident: another process holds part of the GPU):
+        // the seeds would be computed from stale outputs -- poison the loss instead, pinn_get_status reports it
+        if (!arrived) lsum[0] = __builtin_nan("");
       }
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
