@@ -80,7 +80,8 @@ __device__ __forceinline__ agd agd_put(const double x) {
 // inside inline asm, so nothing would keep the v_accvgpr_write the required wait states behind the MFMA that
 // produces x (observed: stale low words, 1e-8 relative errors).  `after` must be the result of a compiler-visible
 // VALU instruction that reads x: the extra operand orders the asm behind that instruction, whose own hazard wait
-// the compiler did insert.
+// the compiler did insert.  tests/helpers/isa_lint.py checks the built code for exactly this (every accvgpr move of
+// the library against every matrix instruction in front of it, along the control-flow graph).
 __device__ __forceinline__ agd agd_put_after(const double x, const double after) {
 #if PINN_ABLD == 5
   return agd{1, 2};

@@ -92,10 +92,12 @@ __device__ __forceinline__ v4f agpr_get4(const v4f a) {
   return v4f{agpr_get(a.x), agpr_get(a.y), agpr_get(a.z), agpr_get(a.w)};
 }
 
-// one 1-KiB piece global -> LDS (lane i: 16 bytes from g to lds_piece + 16 i), invisible to the compiler
+// one 1-KiB piece global -> LDS (lane i: 16 bytes from g to lds_piece + 16 i), invisible to the compiler -- and so to
+// its hazard recogniser: an LDS-DMA that reads m0 needs one wait state behind the s_mov that wrote it (LLVM
+// checkReadM0Hazards, gfx9), hence the s_nop INSIDE the asm; tests/helpers/isa_lint.py checks the built library for it.
 __device__ __forceinline__ void lds_dma_b128(const float* g, float* lds_piece) {
   const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_piece;
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(base) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(base) : "memory", "m0");
 }
 // makes the compiler wait for a loaded value here
 __device__ __forceinline__ void consume4(v4f& v) { asm volatile("" : "+v"(v)); }
