@@ -204,6 +204,9 @@ int pinn_get_kernel_path(pinn_ctx* c, int* path);
 int pinn_debug_stamps(pinn_ctx* c, long long* out, int64_t cap, int64_t* n_waves);
 /* Profiling build only: s_memtime stamps of the most recent k_lbc_coef launch (7 used of 16). */
 int pinn_debug_coef_stamps(long long* out16);
+/* Profiling build only: s_memtime stamps of workgroup 0's second group in the most recent k_t16_fused launch,
+ * out[wave 0..7][64] (profiles/t16f_stamps.py names the phases). */
+int pinn_debug_t16f_stamps(long long* out512);
 
 #ifdef __cplusplus
 }

@@ -1902,6 +1902,18 @@ int pinn_debug_coef_stamps(long long* out16) {
 #endif
 }
 
+int pinn_debug_t16f_stamps(long long* out512) {
+#ifdef PINN_STAMPS
+  REQUIRE(out512, "null");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out512, HIP_SYMBOL(g_t16f_stamps), 8 * 64 * sizeof(long long)));
+  return 0;
+#else
+  (void)out512;
+  return fail(PINN_EUNSUPPORTED, "built without -DPINN_STAMPS (profiling build only)");
+#endif
+}
+
 int pinn_get_kernel_path(pinn_ctx* c, int* path) {
   REQUIRE(c && path, "null");
   *path = c->path;

@@ -34,6 +34,23 @@
 
 namespace pinn {
 
+// Profiling build (-DPINN_STAMPS, libpinn_hip_stamps.so): s_memtime at the phase boundaries of workgroup 0's SECOND
+// group, every wave; read back through pinn_debug_t16f_stamps (profiles/t16f_stamps.py).  Product build: nothing.
+#ifdef PINN_STAMPS
+__device__ long long g_t16f_stamps[8 * 64];
+#define FSTAMP(i)                                                                                         \
+  do {                                                                                                    \
+    if (blockIdx.x == 0 && grp == (int)gridDim.x && lane == 0) g_t16f_stamps[wave * 64 + (i)] = clock64(); \
+  } while (0)
+#define KSTAMP(i)                                                                                         \
+  do {                                                                                                    \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_t16f_stamps[(threadIdx.x >> 6) * 64 + (i)] = clock64(); \
+  } while (0)
+#else
+#define FSTAMP(i) do { } while (0)
+#define KSTAMP(i) do { } while (0)
+#endif
+
 // dynamic LDS of the kernel; t16_fused_small_in_lds: the per-feature gradients of the biases and of layer 0 ((H + 2) W
 // doubles) fit behind the fixed areas and are accumulated there over the groups instead of in the row
 inline size_t t16_fused_fixed_doubles() { return (size_t)2 * T16Geo<8>::TILE * 4 + 2 * 8 * 2 * 16 * 4 + 2 * 16 * 4 + 32 + 7 * 16; }
@@ -90,7 +107,13 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   real c1 = real(1), c2 = nu;
   if (PDE == 1) { c1 = th[nd.n_net]; c2 = exp_r(th[nd.n_net + 1]); }
 
-  if (!accumulate) {
+  KSTAMP(60);
+  // A fresh row (accumulate == 0) is STORED entry by entry at the end of the kernel -- every entry has exactly one owner
+  // there -- instead of zeroed here and added into: the zero fill (246 KB per workgroup) and the read half of the final
+  // read-modify-write were 12 k + ~65 k of the kernel's 995 k cycles (profiles/r04_t16f_stamps_v5.txt).  Only when the
+  // small gradients do not fit in LDS (H = 4, widths 126..128) are they still accumulated in the row per group.
+  const bool direct = !accumulate && small_lds;
+  if (!accumulate && !direct) {
     for (int i = tid0; i < R; i += THREADS) row[i] = real(0);
     __syncthreads();                          // (global stores of one workgroup, read back by the same workgroup)
   }
@@ -100,6 +123,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
 
   // (k_t16_fwd keeps dense 0's parameters and the output layer's k-slice in registers across groups: 40 registers
   //  this kernel needs for the stash -- they are re-read from L2 per group instead)
+  KSTAMP(61);
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int lp0 = grp * 16;
     // The lane index is re-read through an opaque asm once per group: every per-lane address of the body (six layer
@@ -124,7 +148,20 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     t16_gemm_l2<real, decltype(tr_tag)::value, PD, acc_t>(Wm, Bt, W, 16 * wave + m, m, g, a0, a1, a2, a3);
   };
 
+  // Per-feature sums over the group's 16 points (bias gradients, layer 0's gradients): the lanes that PRODUCE a z_bar
+  // entry (row j, point m) sum it over the 16 lanes of their DPP row and lane m == 0 adds it to the feature's slot -- no
+  // extra pass over the tile by 100 threads of waves 0 / 1 while the other waves wait (2 k cycles per layer on the
+  // critical path, profiles/r04_t16f_stamps_v5.txt).  One owner lane per (slot, feature): no synchronisation.
+  auto feature_add = [&](const int slot, real* __restrict__ row_slot, const int j, const real x) {
+    const real sum = row16_sum(x);
+    if (m == 0 && j < W) {
+      if (small_lds) gsm[slot * W + j] += sum;
+      else row_slot[j] += sum;
+    }
+  };
+
     // =========================================================================================== forward sweep
+    FSTAMP(0);
     real a0e[NI];                             // layer 0's tanh values of this thread's (feature, point) items: the reverse
                                               // sweep needs them twice more (a tanh is ~45 instructions; k_t16_bwd reads S)
     {  // dense 0: items (feature j, point pe), point fastest
@@ -148,9 +185,11 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     V4 stash[H - 1][4];                       // hidden layers 1..H-1, this lane's four rows of its wave's tile
     V4* Tin = T0;
     V4* Tout = T1;
+    FSTAMP(1);
 #pragma unroll
     for (int l = 1; l < H; ++l) {
       __syncthreads();                        // Tin published
+      FSTAMP(2 + 3 * (l - 1));
       if (!tile_live) {                       // tile entirely in the padding: zeros
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -167,6 +206,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         }
         acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
         gemm(th + nd.off_w[l], Tin, std::false_type{}, a0, a1, a2, a3);
+        FSTAMP(3 + 3 * (l - 1));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * wave + TR::out_row(lane, r);           // feature; the point is m
@@ -180,9 +220,11 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           Tout[j * PD + m] = c;
         }
       }
+      FSTAMP(4 + 3 * (l - 1));
       V4* tmp = Tin; Tin = Tout; Tout = tmp;
     }
     __syncthreads();
+    FSTAMP(14);
     {  // linear output layer: thread = (k-slice ks8, output o, point pe); the slices are summed through LDS
       const int o = (tid >> 4) & 1, ks8 = tid >> 5;
       V4 acc{0, 0, 0, 0};
@@ -207,6 +249,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         seeds[o * 16 + pe] = tot;                                 // the group's own outputs stay on chip for the seeds
       }
     }
+    FSTAMP(15);
     if (grp < n_bgroups) {
       // Periodic-boundary seeds read the outputs of a PARTNER point, which another workgroup may own.  The boundary
       // points fill the first n_bgroups groups of the set, each the FIRST group of its workgroup (grid >= n_bgroups,
@@ -232,6 +275,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     } else {
       __syncthreads();                        // the group's outputs are in memory (written and read by this workgroup)
     }
+    FSTAMP(16);
     // =========================================================================================== reverse sweep
     if (tid < 16) {
       const int pt = base + lp0 + tid;
@@ -245,6 +289,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       lsum[80 + tid] += sb[0].x; lsum[96 + tid] += sb[1].x;
     }
     __syncthreads();
+    FSTAMP(17);
     // Tin = outputs of layer H-1 (inputs of dense H), Tout = outputs of layer H-2 (inputs of layer H-1): the reverse
     // sweep starts with TI = Tout (A operand of dW_{H-1}) and overwrites Tin with the adjoint of layer H-1's
     // pre-activations
@@ -271,6 +316,7 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
         gwacc[r][0] += gw0;
         gwacc[r][1] += gw1;
         Bcur[j * PD + m] = zb;
+        feature_add(H - 2, row + nd.off_b[H - 1], j, zb.x);      // bias gradient of layer H-1
       }
     }
     // Weight-gradient tiles of a layer, dealt so that every SIMD carries the same number of matrix instructions: a
@@ -285,9 +331,11 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
       if (wave < ntl) { t_lo = wave * base_n + (wave < extra ? wave : extra); t_hi = t_lo + base_n + (wave < extra ? 1 : 0); }
       else { t_lo = rest + (wave - ntl) * per_idle; t_hi = t_lo + per_idle; }
     }
+    FSTAMP(18);
 #pragma unroll
     for (int d = H - 1; d >= 1; --d) {
       __syncthreads();                        // Bcur (z_bar of layer d), TI (inputs of layer d) published
+      FSTAMP(19 + 6 * (H - 1 - d));
       // ---- dW_d[k][j] += sum over the 64 (point, channel) rows: tiles tau = (rt, ct), A = TI rows k, B = z_bar rows j.
       // The row entries of the NEXT tile are requested before this tile's matrix instructions (a fetch from the
       // 63 MB of partial rows costs 2-3 k cycles, a tile's 16 matrix instructions last 1 k)
@@ -330,18 +378,16 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
 #endif
         old = nxt;
       }
-      if (tid < W) {                          // bias gradient of layer d
-        real sb_ = 0;
-        for (int p = 0; p < 16; ++p) sb_ += Bcur[tid * PD + p].x;
-        if (small_lds) gsm[(d - 1) * W + tid] += sb_;
-        else row[nd.off_b[d] + tid] += sb_;
-      }
+      FSTAMP(20 + 6 * (H - 1 - d));
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p] into registers -- no barrier between the
       // gradient tiles and this GEMM (both only READ the two tiles), so the waves of a SIMD drift apart and one's
       // matrix instructions run under the other's loads and stores
+      FSTAMP(21 + 6 * (H - 1 - d));
       acc_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
       if (tile_live) gemm(th + nd.off_w[d], Bcur, std::true_type{}, a0, a1, a2, a3);
+      FSTAMP(22 + 6 * (H - 1 - d));
       __syncthreads();                        // every wave is done reading TI and Bcur: both are rewritten
+      FSTAMP(23 + 6 * (H - 1 - d));
       {  // ... straight through layer d-1's tanh into TI (the next layer's z_bar)
         V4* const Bnxt = TI;
 #pragma unroll
@@ -355,7 +401,16 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
                                  : V4{TI[k * PD + m].x, sx * th[nd.off_w[0] + k], st * th[nd.off_w[0] + W + k], real(0)};
             v = preact_adjoint(sk, V4{a0[r], a1[r], a2[r], a3[r]});
           }
-          Bnxt[k * PD + m] = v;
+          if (d >= 2) {
+            Bnxt[k * PD + m] = v;
+            feature_add(d - 2, row + nd.off_b[d >= 2 ? d - 1 : 0], k, v.x);   // bias gradient of layer d-1
+          } else {
+            // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st); its z_bar goes nowhere else -- not written to the tile
+            const real hxm = hxy[m], htm = hxy[16 + m];
+            feature_add(H - 1, row + nd.off_w[0], k, hxm * v.x + sx * v.y);
+            feature_add(H, row + nd.off_w[0] + W, k, htm * v.x + st * v.z);
+            feature_add(H + 1, row + nd.off_b[0], k, v.x);
+          }
         }
       }
       if (d >= 2) {                           // inputs of layer d-1 = output channels of layer d-2
@@ -380,56 +435,60 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           }
         }
       }
+      FSTAMP(24 + 6 * (H - 1 - d));
       V4* tmp = Bcur; Bcur = TI; TI = tmp;     // roles swap: the old TI holds z_bar, the old Bcur the inputs
     }
-    __syncthreads();                          // z_bar of dense 0 published
-    if (tid < W) {  // dense 0: inputs (hx, ht), p0 = (sx, 0), q0 = (0, st)
-      real gx = 0, gt = 0, gb = 0;
-      for (int p = 0; p < 16; ++p) {
-        const V4 zb = Bcur[tid * PD + p];
-        gx += hxy[p] * zb.x + sx * zb.y;
-        gt += hxy[16 + p] * zb.x + st * zb.z;
-        gb += zb.x;
-      }
-      if (small_lds) {
-        gsm[(H - 1) * W + tid] += gx; gsm[H * W + tid] += gt; gsm[(H + 1) * W + tid] += gb;
-      } else {
-        row[nd.off_w[0] + tid] += gx;
-        row[nd.off_w[0] + W + tid] += gt;
-        row[nd.off_b[0] + tid] += gb;
-      }
-    }
-    __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group
+    FSTAMP(41);
+    __syncthreads();                          // seeds / hxy / tiles are rewritten by the next group; gsm published
+    FSTAMP(42);
   }
+  KSTAMP(62);
+  __syncthreads();                            // (gsm zeroed / accumulated by other lanes than the ones that copy it out)
+  auto put = [&](real* __restrict__ dst, const real v) {
+    if (direct) *dst = v; else *dst += v;
+  };
   {  // the on-chip sums -> the partial row
     const int lane = tid0 & 63, m = lane & 15;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {             // output-layer weights: this lane's rows, summed over the 16 points
       const int j = 16 * wave + TR::out_row(lane, r);
-      const real g0 = sum16(gwacc[r][0]), g1 = sum16(gwacc[r][1]);
+      const real g0 = row16_sum(gwacc[r][0]), g1 = row16_sum(gwacc[r][1]);
       if (m == 0 && j < W) {
-        row[nd.off_w[H] + j * NO] += g0;
-        if (NO > 1) row[nd.off_w[H] + j * NO + 1] += g1;
+        put(row + nd.off_w[H] + j * NO, g0);
+        if (NO > 1) put(row + nd.off_w[H] + j * NO + 1, g1);
       }
     }
-    if (small_lds && tid0 < W) {              // (same thread accumulated and reads: no barrier needed)
+    if (small_lds && tid0 < W) {
 #pragma unroll
-      for (int d = 1; d < H; ++d) row[nd.off_b[d] + tid0] += gsm[(d - 1) * W + tid0];
-      row[nd.off_w[0] + tid0] += gsm[(H - 1) * W + tid0];
-      row[nd.off_w[0] + W + tid0] += gsm[H * W + tid0];
-      row[nd.off_b[0] + tid0] += gsm[(H + 1) * W + tid0];
+      for (int d = 1; d < H; ++d) put(row + nd.off_b[d] + tid0, gsm[(d - 1) * W + tid0]);
+      put(row + nd.off_w[0] + tid0, gsm[(H - 1) * W + tid0]);
+      put(row + nd.off_w[0] + W + tid0, gsm[H * W + tid0]);
+      put(row + nd.off_b[0] + tid0, gsm[(H + 1) * W + tid0]);
     }
   }
-  {  // tile-major scratch -> the partial row (every entry written by the lane that owns it: no barrier needed)
+  {  // tile-major scratch -> the partial row (every entry of a hidden-layer matrix has exactly one owner lane), four
+     // tiles in flight per wave: one tile at a time was a chain of ~18 dependent memory round trips per wave
     const int lane = tid0 & 63, m = lane & 15;
-    for (int e = wave; e < (H - 1) * n_tiles; e += NWV) {
-      const int dl = e / n_tiles, tau = e - dl * n_tiles, rt = tau / ntl, ct = tau - rt * ntl, j = 16 * ct + m;
-      const V4 v = reinterpret_cast<const V4*>(gs)[(size_t)e * 64 + lane];
-      const real vr[4] = {v.x, v.y, v.z, v.w};
+    const int n_e = (H - 1) * n_tiles;
+    const V4* __restrict__ gsv = reinterpret_cast<const V4*>(gs) + lane;
+    for (int e0 = wave; e0 < n_e; e0 += 4 * NWV) {
+      V4 v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * rt + TR::out_row(lane, r);
-        if (k < W && j < W) row[nd.off_w[dl + 1] + k * W + j] += vr[r];      // (+ the zeros / the earlier chunks' sums)
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NWV;
+        v[u] = gsv[(size_t)(e < n_e ? e : e0) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = e0 + u * NWV;
+        if (e >= n_e) break;
+        const int dl = e / n_tiles, tau = e - dl * n_tiles, rt = tau / ntl, ct = tau - rt * ntl, j = 16 * ct + m;
+        const real vr[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 16 * rt + TR::out_row(lane, r);
+          if (k < W && j < W) put(row + nd.off_w[dl + 1] + k * W + j, vr[r]);   // (accumulate: + the earlier chunks' sums)
+        }
       }
     }
   }
@@ -440,12 +499,14 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
     dl_acc[0] = sum16(lsum[48 + tid0]); dl_acc[1] = sum16(lsum[64 + tid0]);
     gb_acc[0] = sum16(lsum[80 + tid0]); gb_acc[1] = sum16(lsum[96 + tid0]);
     if (tid0 == 0) {
-      row[nd.n_theta + 0] += l_acc[0]; row[nd.n_theta + 1] += l_acc[1]; row[nd.n_theta + 2] += l_acc[2];
-      row[nd.off_b[H]] += gb_acc[0];
-      if (NO > 1) row[nd.off_b[H] + 1] += gb_acc[1];
-      if (PDE == 1) { row[nd.n_net] += dl_acc[0]; row[nd.n_net + 1] += dl_acc[1]; }
+      put(row + nd.n_theta + 0, l_acc[0]); put(row + nd.n_theta + 1, l_acc[1]); put(row + nd.n_theta + 2, l_acc[2]);
+      for (int i = nd.n_theta + 3; direct && i < R; ++i) row[i] = real(0);       // (padding of the row)
+      put(row + nd.off_b[H], gb_acc[0]);
+      if (NO > 1) put(row + nd.off_b[H] + 1, gb_acc[1]);
+      if (PDE == 1) { put(row + nd.n_net, dl_acc[0]); put(row + nd.n_net + 1, dl_acc[1]); }
     }
   }
+  KSTAMP(63);
 }
 
 }  // namespace pinn

@@ -52,6 +52,16 @@ __device__ __forceinline__ double read_lane(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Sum over the 16 lanes of a DPP row (four vector-ALU steps, no LDS traffic); every lane of the row gets it.
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+  v += dpp_mov<DPP_QUAD_XOR1>(v);
+  v += dpp_mov<DPP_QUAD_XOR2>(v);
+  v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_ROW_MIRROR>(v);
+  return v;
+}
+
 // Sum over the 64 lanes of a wave; the result is wave-uniform (read back from lane 63).
 // Fixed combination order -> bit-reproducible run to run.
 template <typename T>
