@@ -46,6 +46,11 @@ namespace pinn {
 #endif                         // layer's stash, ahead of the matrix instructions -- measured 8 us SLOWER on cfg 4 float64
                                // (605 vs 597 us, same box, profiles/r03_t16_ab.txt): with two waves per SIMD the other
                                // wave already covers those latencies and the extra live registers cost more
+#ifndef T16_B_AHEAD
+#define T16_B_AHEAD 1          // LDS operands of the layer GEMMs requested this many k-steps ahead (1 or 2).  Two: 254-256
+                               // VGPRs in k_t16_fused and 1.5 % SLOWER there (same box, cfg 4 float64 410.5 vs 417.3 us per
+                               // step), within +-0.5 % on the two-kernel sweeps: the LDS latency is already covered
+#endif
 #ifndef T16_GEMM4
 #define T16_GEMM4 1            // 1: the four-wave variants (widths <= 64) also use t16_gemm_l2 / the two-chain gradient tiles
 #endif                         // where their weights come from L2: same-box A/B (profiles/r04_t16_gemm4_ab.txt) 2x50^4x1 f64
@@ -131,11 +136,18 @@ __device__ __forceinline__ void t16_gemm_l2(const real* __restrict__ Wm, const v
   real w0[4], w1[4], w2[4];
   if (nfc > 0) { fetch(0, w0); fetch(1, w1); }
   V4 bc = bp[0];
+#if T16_B_AHEAD == 2
+  V4 bn = bp[4 * PD];
+#endif
   auto chunk = [&](const int c, real (&cur)[4], real (&fill)[4]) {
     fetch(c + 2, fill);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+#if T16_B_AHEAD == 2
+      const V4 bn2 = bp[(4 * c + u + 2) * 4 * PD];                // rows of the k-step after next (inside the LDS allocation)
+#else
       const V4 bn = bp[(4 * c + u + 1) * 4 * PD];                 // next k-step's rows (always inside the tile)
+#endif
       __builtin_amdgcn_sched_barrier(0);
       a0 = t16_mfma<real, acc_t>(cur[u], bc.x, a0);
       a1 = t16_mfma<real, acc_t>(cur[u], bc.y, a1);
@@ -143,6 +155,9 @@ __device__ __forceinline__ void t16_gemm_l2(const real* __restrict__ Wm, const v
       a3 = t16_mfma<real, acc_t>(cur[u], bc.w, a3);
       __builtin_amdgcn_sched_barrier(0);
       bc = bn;
+#if T16_B_AHEAD == 2
+      bn = bn2;
+#endif
     }
   };
   for (int c = 0; c < nfc; c += 3) {

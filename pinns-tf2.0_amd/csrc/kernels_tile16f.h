@@ -349,18 +349,27 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
 #endif
       };
       V4 old = fetch_old(t_lo);
+      // (rt, ct) walk the range incrementally (a division per tile is ~40 scalar instructions); the first operands of
+      // the NEXT tile are requested with the last quarter of this one, so no tile starts with an exposed LDS round trip.
+      // (Tried: the old sums as the initial value of the first accumulator chain -- one vector add per entry less, but
+      //  the tile's FIRST matrix instruction then waits for a fetch issued only one tile earlier: 406 -> 425 us per step.)
+      int rt = t_lo / ntl, ct = t_lo - rt * ntl;
+      const V4* __restrict__ ap = TI + (16 * rt + m) * PD + g;
+      const V4* __restrict__ bq = Bcur + (16 * ct + m) * PD + g;
+      V4 A = ap[0], B = bq[0];
       for (int tau = t_lo; tau < t_hi; ++tau) {
-        const int rt = tau / ntl, ct = tau - rt * ntl;
         const V4 nxt = fetch_old(tau + 1);
+        int rtn = rt, ctn = ct + 1;
+        if (ctn == ntl) { ctn = 0; ++rtn; }
+        if (tau + 1 >= t_hi) { rtn = rt; ctn = ct; }               // (last tile: a harmless re-read)
+        const V4* __restrict__ apn = TI + (16 * rtn + m) * PD + g;
+        const V4* __restrict__ bqn = Bcur + (16 * ctn + m) * PD + g;
         // two accumulator chains (even / odd quarter of the 16 points) instead of one 16-deep dependent chain, and the
         // operands of quarter s4 + 1 requested before the matrix instructions of quarter s4
         acc_t acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
-        const V4* __restrict__ ap = TI + (16 * rt + m) * PD + g;
-        const V4* __restrict__ bq = Bcur + (16 * ct + m) * PD + g;
-        V4 A = ap[0], B = bq[0];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          const V4 An = ap[s4 < 3 ? 4 * (s4 + 1) : 0], Bn = bq[s4 < 3 ? 4 * (s4 + 1) : 0];
+          const V4 An = s4 < 3 ? ap[4 * (s4 + 1)] : apn[0], Bn = s4 < 3 ? bq[4 * (s4 + 1)] : bqn[0];
           __builtin_amdgcn_sched_barrier(0);
           acc = t16_mfma<real, acc_t>(A.x, B.x, acc);
           acc2 = t16_mfma<real, acc_t>(A.y, B.y, acc2);
@@ -369,14 +378,15 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
           __builtin_amdgcn_sched_barrier(0);
           A = An; B = Bn;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
 #if T16_ABL == 3
         if (acc[0] == real(-1.2345e300)) gsd[(size_t)tau * 64] = V4{acc[0], acc[1], acc[2], acc[3]};
 #else
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
         gsd[(size_t)tau * 64] = V4{old.x + acc[0], old.y + acc[1], old.z + acc[2], old.w + acc[3]};
 #endif
         old = nxt;
+        rt = rtn; ct = ctn; ap = apn; bq = bqn;
       }
       FSTAMP(20 + 6 * (H - 1 - d));
       // ---- adjoint of layer d-1: in_bar[k][p] = sum_j W_d[k][j] z_bar[j][p] into registers -- no barrier between the
