@@ -142,7 +142,9 @@ __global__ __launch_bounds__(512) void k_t16_fused(NetDesc nd, SetDesc sd, const
   // instructions.
   // (Tried and dropped: requesting a GEMM's first two weight chunks ahead of the phase before it -- the previous layer's
   //  tanh epilogue, the gradient tiles -- so that no GEMM starts with a cold L2 round trip: 256 VGPRs instead of 238
-  //  and 449 vs 446 us per step, same box: with two waves per SIMD the other wave already covers that latency.)
+  //  and 449 vs 446 us per step, same box: with two waves per SIMD the other wave already covers that latency.  Second
+  //  attempt, right in front of the phase barrier only: 256 VGPRs + 40 B of scratch, 410.6 vs 404.3 us -- the kernel has
+  //  no 16 registers to spare anywhere near a GEMM; profiles/r04_t16f_dw_pipeline_ab.txt.)
   auto gemm = [&](const real* __restrict__ Wm, const V4* __restrict__ Bt, auto tr_tag, acc_t& a0, acc_t& a1,
                   acc_t& a2, acc_t& a3) {
     t16_gemm_l2<real, decltype(tr_tag)::value, PD, acc_t>(Wm, Bt, W, 16 * wave + m, m, g, a0, a1, a2, a3);
