@@ -69,7 +69,7 @@ HBM_PEAK_GBPS = 8000.0
 MIN_TIMED_MS = float(os.environ.get("PINN_BENCH_MIN_TIMED_MS", "3000"))   # per leg: long enough for the driver's
 MAX_BLOCKS = 8000                                                         # 5-second GPU-busy sampler to see the legs
 KERNEL_NAMES = {2: "pinn::k_fused20m", 1: "pinn::k_fused20", 7: "pinn::k_fused20d", 0: "pinn::k_forward+k_backward",
-                3: "pinn::k_wide_fwd+k_wide_bwd"}
+                3: "pinn::k_wide_fwd+k_wide_bwd", 8: "pinn::k_t16_fused"}
 BURGERS_ADAM = (0.03, 0.9, 0.999, 1e-7)                            # 1d-burgers/inf_cont_burgers.py:35-37 (eps None = Keras 1e-7)
 BURGERS_LBFGS = (0.8, 50)                                          # :39-41
 LAUNCH_FLOOR_US = 4.5                                              # a trivial launch on this stream
@@ -194,6 +194,8 @@ def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None, flops=None, n_
     path = eng.kernel_path()
     single_kernel = path in (1, 2, 7)
     wgs = min(tiles, n_cu) if path in (2, 7) else tiles
+    if path in (3, 8):                       # persistent workgroups over 16-point groups, one per CU
+        wgs = min(4 * tiles, n_cu)
     return {
         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
         "frac": (achieved / peak) if achieved else None,
@@ -211,7 +213,7 @@ def roofline(eng, tim, dtype, n_f_local, n_u_local, traffic=None, flops=None, n_
         # is the latency of a single workgroup (neither roof is reachable); many tiles per CU = throughput regime
         "workgroups": wgs, "compute_units": n_cu, "tiles_per_workgroup": tiles / max(wgs, 1),
         "regime": ("latency: %d workgroups on %d CUs, one tile deep" % (wgs, n_cu)) if (single_kernel and tiles <= n_cu)
-                  else "throughput: %.1f tiles per workgroup" % (tiles / max(wgs, 1)),
+                  else "throughput: %.1f tiles (64 points) per workgroup" % (tiles / max(wgs, 1)),
         "launch_floor_us": LAUNCH_FLOOR_US,
     }
 
