@@ -13,6 +13,10 @@ What each fixture pins, and from which reference code:
   schrodinger_data.json  schrodingerutil.prep_data (1dcomplex-schrodinger/schrodingerutil.py:21-61)
   burgers_eval.npz       BurgersInformedNN.loss/f_model + NeuralNetwork.get_loss_and_flat_grad
                          (1d-burgers/inf_cont_burgers.py:59-98, utils/neuralnetwork.py:91-103)
+  burgers_eval_1e6.npz   BASELINE configs[4] (N_f = 10^6): the same get_loss_and_flat_grad closure evaluated on the eight
+                         125 000-point blocks an 8-rank launch shards the set into (one reference model per block; the
+                         loss is a mean, so the N_f = 10^6 value is the block average) at the canonical and a perturbed
+                         weight vector, + the base class's plain-MSE closure (utils/neuralnetwork.py:51-52) for the data term
   burgers_adam.npz       NeuralNetwork.tf_optimization_step (utils/neuralnetwork.py:112-116)
   burgers_lbfgs.npz      custom_lbfgs.lbfgs driven by the PINN closure (utils/custom_lbfgs.py:39-236)
   lbfgs_kat.json         custom_lbfgs.lbfgs on a 6-D analytic function
@@ -185,6 +189,57 @@ def gen_burgers_eval_adam_lbfgs():
             final_loss_global=float(custom_lbfgs.final_loss))
         print("burgers_lbfgs%s: f_hist[-1]=%.10e n_eval=%d logs=%d" % (
             tag, float(f_hist[-1]), n_eval, len(logs)))
+
+
+def perturbed_weights(w0):
+    """a deterministic second evaluation point: every entry moved by up to 5 % of the largest kernel entry (biases leave 0)"""
+    k = np.arange(w0.size, dtype=np.float64)
+    return w0 + 0.05 * np.max(np.abs(w0)) * np.sin(1.0 + 0.37 * k)
+
+
+def gen_burgers_eval_1e6():
+    """BASELINE configs[4]: N_f = 10^6 (1d-burgers/inf_cont_burgers.py:59-90 on burgersutil.py:122's Latin hypercube).
+    The reference evaluates mean(f^2) over all points in one tape; that graph does not fit this container's memory
+    over the torch stand-in, and the loss is a mean: L = mse_u + (1/N) sum_c sum_{i in c} f_i^2 = sum_c (n_c/N) L_c with
+    L_c = the reference's own loss of a model built on block c.  The blocks are the contiguous eight an 8-rank launch
+    shards the set into (pinn_native.parallel.shard_bounds), so the fixture pins every rank's shard AND their sum.
+    The classes come from the unmodified script (run once at its default size); the set is prep_data's with the
+    script's seed.  Recorded per block: the closure's (loss, flat grad) at w0 (canonical init) and w1 (perturbed)."""
+    import tensorflow as tf
+    import burgersutil
+    g, _ = run_reference_script("1d-burgers/inf_cont_burgers.py", burgers_hp())
+    Cls, Base, Logger = g["BurgersInformedNN"], g["NeuralNetwork"], g["Logger"]
+    hp = burgers_hp(N_f=1000000)
+    np.random.seed(1234)                                   # the script's own seed (inf_cont_burgers.py:13)
+    r = burgersutil.prep_data("1d-burgers/data/burgers_shock.mat", hp["N_u"], hp["N_f"], noise=0.0)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    w0 = g["pinn"].get_weights().numpy()                   # the canonical init (first model of the process, seed 1234)
+    ws = {"w0": w0, "w1": perturbed_weights(w0)}
+    N, R = X_f.shape[0], 8
+    bounds = [(N * k // R, N * (k + 1) // R) for k in range(R)]
+    out = {"bounds": np.array(bounds), "sha_X_f": sha16(X_f), "sha_X_u": sha16(X_u), "sha_w0": sha16(w0), "w1": ws["w1"],
+           "X_f_first": X_f[:4], "X_f_last": X_f[-4:], "hp": json.dumps(hp), "nu": 0.01 / np.pi}
+    with contextlib.redirect_stdout(io.StringIO()):
+        logger = Logger(hp)
+        for name, w in ws.items():
+            losses, grads = [], []
+            for lo, hi in bounds:
+                pinn = Cls(hp, logger, X_f[lo:hi], ub, lb, nu=0.01 / np.pi)
+                closure = pinn.get_loss_and_flat_grad(pinn.tensor(X_u), pinn.tensor(u))
+                lv, gv = closure(tf.convert_to_tensor(w))
+                losses.append(float(lv))
+                grads.append(gv.numpy())
+                del pinn, closure
+            base = Base(hp, logger, ub, lb)                # the base class: loss = plain data misfit (:51-52)
+            lv, gv = base.get_loss_and_flat_grad(base.tensor(X_u), base.tensor(u))(tf.convert_to_tensor(w))
+            out["block_loss_" + name], out["block_grad_" + name] = np.array(losses), np.array(grads)
+            out["mse_u_" + name], out["grad_mse_u_" + name] = float(lv), gv.numpy()
+            wt = np.array([(hi - lo) / N for lo, hi in bounds])
+            out["loss_" + name] = float(np.dot(wt, losses))
+            out["grad_" + name] = (wt[:, None] * np.array(grads)).sum(0)
+    np.savez_compressed(os.path.join(HERE, "burgers_eval_1e6.npz"), **out)
+    print("burgers_eval_1e6: loss(w0)=%.17g mse_u=%.17g loss(w1)=%.17g |g(w0)|1=%.10e" % (
+        out["loss_w0"], out["mse_u_w0"], out["loss_w1"], float(np.abs(out["grad_w0"]).sum())))
 
 
 def gen_lbfgs_kat():
@@ -604,6 +659,8 @@ def main():
         gen_logger_bytes()
     if "burgers" in which:
         gen_burgers_eval_adam_lbfgs()
+    if "burgers_1e6" in which or not sys.argv[1:]:
+        gen_burgers_eval_1e6()
     if "ide" in which:
         gen_burgers_ide_eval()
         gen_burgers_ide_run()

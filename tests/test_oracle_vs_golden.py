@@ -33,6 +33,46 @@ def test_burgers_eval(burgers_sets, tag, N_u, N_f):
     assert np.max(np.abs(up[::257, 0] - g["u_pred_stride"])) < 1e-14
 
 
+def test_burgers_eval_1e6_blocks(burgers_sets):
+    """BASELINE configs[4] (N_f = 10^6): the oracle, evaluated in chunks with the global denominator, against the
+    reference's own closure on the 125 000-point blocks (tests/golden/make_golden.py gen_burgers_eval_1e6): the full
+    set at the canonical weights, two single blocks at the perturbed ones, and the base class's data term"""
+    g = np.load(golden("burgers_eval_1e6.npz"))
+    hp = json.loads(str(g["hp"]))
+    layers, N = hp["layers"], hp["N_f"]
+    r = burgers_sets(hp["N_u"], N)
+    X_u, u, X_f, ub, lb = r[7], r[8], r[9], r[10], r[11]
+    assert np.array_equal(X_f[:4], g["X_f_first"]) and np.array_equal(X_f[-4:], g["X_f_last"])
+    w0 = init.glorot_flat(layers)
+
+    def residual_part(w, lo, hi):
+        L, G = 0.0, 0.0
+        for a in range(lo, hi, 62500):
+            l, gr, _ = pde.burgers_loss_grad(w, layers, lb, ub, X_f[a:min(a + 62500, hi)], X_u, u, NU, n_f_total=N,
+                                             with_data=False)
+            L, G = L + l, G + gr
+        return L, G
+
+    def data_part(w):
+        l, gr, _ = pde.burgers_loss_grad(w, layers, lb, ub, X_f[:0], X_u, u, NU, n_f_total=N, with_data=True)
+        return l, gr
+    # full set, canonical weights
+    (Lr, Gr), (Lu, Gu) = residual_part(w0, 0, N), data_part(w0)
+    assert abs(Lu - float(g["mse_u_w0"])) < 1e-15 and rel(Gu, g["grad_mse_u_w0"]) < 1e-13
+    assert abs(Lr + Lu - float(g["loss_w0"])) < 1e-14
+    assert rel(Gr + Gu, g["grad_w0"]) < 1e-13
+    # single blocks at the perturbed weights: the reference's block model gives mse_u + mean_c(f^2)
+    w1 = g["w1"]
+    Lu, Gu = data_part(w1)
+    assert abs(Lu - float(g["mse_u_w1"])) < 1e-15
+    for k in (2, 7):
+        lo, hi = (int(v) for v in g["bounds"][k])
+        Lr, Gr = residual_part(w1, lo, hi)
+        share = (hi - lo) / N
+        assert abs(Lr / share + Lu - float(g["block_loss_w1"][k])) < 1e-14
+        assert rel(Gr / share + Gu, g["block_grad_w1"][k]) < 1e-13
+
+
 def test_burgers_known_values_from_survey(burgers_sets):
     """SURVEY.md Appendix C.2 figures (recorded independently of this repo's fixtures)."""
     g = np.load(golden("burgers_eval.npz"))
