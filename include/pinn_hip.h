@@ -47,7 +47,8 @@ enum {
 /* diagnostics */
 const char* pinn_last_error(void);
 int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6; 3: + pinn_residual_at;
-                                 4: + pinn_error_l2, pinn_get_status; 5: + pinn_runtime_versions, pinn_debug_t16_deal */
+                                 4: + pinn_error_l2, pinn_get_status; 5: + pinn_runtime_versions, pinn_debug_t16_deal;
+                                 6: + pinn_adam_enqueue / _collect, pinn_lbfgs_enqueue / _collect */
 int pinn_device_count(int* n);
 /* HIP runtime / driver (hipRuntimeGetVersion, hipDriverGetVersion) and RCCL (ncclGetVersion) this process bound; any
  * pointer may be NULL.  No device is touched. */
@@ -128,6 +129,19 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
                      double tol_x, double max_eval);
 int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged,
                    int* done);
+/* The same two loops with the host one chunk behind the GPU (ABI v6) -- how NeuralNetwork.fit logs every
+ * log_frequency-th epoch (utils/neuralnetwork.py:105-109, utils/logger.py:45-51) without idling the device at a log line:
+ * ..._enqueue puts a chunk of steps into the stream, with asynchronous copies of its losses / log entries / optimiser state
+ * into pinned buffers behind an event, and returns a ticket at once; ..._collect waits for THAT chunk only and hands its
+ * results out, while the chunk enqueued after it is already running.  Up to 4 chunks may be in flight; tickets are
+ * collected in the order they were issued; pinn_lbfgs_begin drops whatever is still in flight (a restart).  The kernels
+ * launched are those of pinn_adam_run / pinn_lbfgs_run on the same chunk sizes, so the results are bit-identical.
+ * pinn_lbfgs_collect: iters / losses hold `cap` entries (enough: the iterations enqueued since the last collect + 1).
+ * An L-BFGS chunk enqueued after the run has ended (done != 0 seen one chunk late) changes nothing on the device. */
+int pinn_adam_enqueue(pinn_ctx* c, int n_steps, int* ticket);
+int pinn_adam_collect(pinn_ctx* c, int ticket, double* losses);
+int pinn_lbfgs_enqueue(pinn_ctx* c, int n_iters, int* ticket);
+int pinn_lbfgs_collect(pinn_ctx* c, int ticket, int cap, int* iters, double* losses, int* n_logged, int* done);
 /* 0: one-workgroup kernel performing the two-loop recursion in the reference's operation order;
  * 1 (default, history <= 61): compact form -- all dot products of an iteration in one parallel
  * kernel, recursion on the Gram matrices.  Same mathematics; rounding differs at 1e-16. */

@@ -150,8 +150,27 @@ struct pinn_ctx {
   double lr = 1e-3, b1 = 0.9, b2 = 0.999, eps = 1e-7;
   int64_t adam_t = 0;
   bool adam_ready = false, adam_want_terms = false;
-  double* loss_hist = nullptr;
+  double* loss_hist = nullptr;       // N_PENDING regions of cap_loss_hist steps x 3 loss parts (one per chunk in flight)
   size_t cap_loss_hist = 0;
+
+  // Chunks of optimiser steps whose results the host has not collected yet (pinn_adam_enqueue / pinn_lbfgs_enqueue ->
+  // ..._collect): the kernels of chunk k+1 are already in the stream while the host reads and logs chunk k, so a logging
+  // boundary costs the GPU nothing.  Each chunk's results travel by asynchronous copies into its own pinned buffers, behind
+  // its own event; tickets are collected in the order they were issued.
+  struct Pending {
+    int kind = 0;                      // 1 Adam, 2 L-BFGS
+    int n = 0;                         // Adam: steps; L-BFGS: length of the log window copied
+    int base = 0, issued_upto = 0;     // L-BFGS: first log entry of the window; iterations issued when it was enqueued
+    bool want_terms = false;
+    hipEvent_t ev = nullptr;
+    double* h_loss = nullptr; size_t cap_loss = 0;      // pinned
+    int* h_iter = nullptr; size_t cap_iter = 0;         // pinned
+    LbfgsState* h_state = nullptr;                      // pinned
+  };
+  static constexpr int N_PENDING = 4;
+  Pending pend[N_PENDING];
+  unsigned long long tickets_issued = 0, tickets_collected = 0;
+  int lb_issued_at_read = 0;           // lb_iters_issued when lb_logged_read was last brought up to date
 
   // L-BFGS
   LbfgsState* lb_state = nullptr;    // two copies (double buffered, see k_lbc_coef_apply); lb_flip = current
@@ -159,12 +178,8 @@ struct pinn_ctx {
   double *lb_x = nullptr, *lb_d = nullptr, *lb_gold = nullptr, *lb_S = nullptr, *lb_Y = nullptr,
          *lb_ro = nullptr, *lb_al = nullptr, *lb_q = nullptr, *lb_log_loss = nullptr;
   int* lb_log_iter = nullptr;
-  // pinned host mirrors read back by pinn_lbfgs_run: state + the log entries the call may have produced, three
-  // asynchronous copies behind ONE stream synchronisation (two blocking hipMemcpy more cost ~25 us per call)
-  LbfgsState* h_lb_state = nullptr;
-  double* h_lb_log_loss = nullptr;
-  int* h_lb_log_iter = nullptr;
-  int h_lb_cap_log = 0;
+  // (the host mirrors read back by pinn_lbfgs_run -- state + the log entries a chunk may have produced, three asynchronous
+  //  copies behind ONE wait; two blocking hipMemcpy more cost ~25 us per call -- are the Pending buffers above)
   int lb_max_iter = 0, lb_ncorr = 0, lb_cap_corr = 0, lb_cap_log = 0, lb_logged_read = 0;
   double lb_lr = 1.0, lb_tol_fun = 0, lb_tol_x = 0, lb_max_eval = 0;
   int lb_iters_issued = 0;
@@ -176,6 +191,7 @@ struct pinn_ctx {
   LbcExtra* lb_ex = nullptr;
   double t16_cost_full = T16_COST_FULL, t16_cost_strip = T16_COST_STRIP;   // k_t16_fused: weights of the gradient-tile dealing (t16_deal; PINN_T16_COSTS)
   long long t16_handover_ticks = 50000000ll;   // bound of that hand-over's wait, 100 MHz ticks (PINN_T16_HANDOVER_TICKS)
+  bool t16_prepass_pinned = false;     // PINN_T16_PREPASS was given: the data-parallel default below does not apply
   bool t16_prepass = false;            // k_t16_fused: boundary outputs by a k_t16_fwd pre-pass instead of the in-kernel hand-over
                                        // (PINN_T16_PREPASS=1, or switched on for good after a hand-over that timed out)
   unsigned int* t16_bsync = nullptr;   // k_t16_fused: boundary-group hand-over counter (never reset; t16_bcount = its value after the last launch)
@@ -941,6 +957,14 @@ static int t16_handover_check(pinn_ctx* c) {
                            "restore the weights (pinn_set_weights) and repeat the call");
 }
 
+// One rank of a data-parallel job: a hand-over time-out would be seen by THIS rank only -- it would fail with PINN_ESTATE and move
+// to the pre-pass while its peers, whose all-reduced loss is poisoned all the same, keep stepping -- and "restore the weights and
+// repeat" cannot be done rank-locally.  So with peers attached the boundary outputs come from the pre-pass from the start (no
+// co-residency assumption at all; one small forward launch per evaluation), unless PINN_T16_PREPASS says otherwise.
+static void t16_prepass_for_ranks(pinn_ctx* c, int n_ranks) {
+  if (n_ranks > 1 && !c->t16_prepass_pinned) c->t16_prepass = true;
+}
+
 // an error raised inside a mailbox kernel (a peer that never delivered) surfaces at the next host sync
 static int xg_check(pinn_ctx* c) {
   if (int rc = t16_handover_check(c)) return rc;
@@ -1088,7 +1112,7 @@ static int predict_values(pinn_ctx* c, int64_t n, int n_pad) {
 extern "C" {
 
 const char* pinn_last_error(void) { return g_err.c_str(); }
-int pinn_abi_version(void) { return 5; }
+int pinn_abi_version(void) { return 6; }
 
 int pinn_device_count(int* n) {
   REQUIRE(n, "null");
@@ -1162,11 +1186,23 @@ int pinn_create(pinn_ctx** out, const int* layers, int n_layers, const double* l
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return fail(PINN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
   // debug knobs of k_t16_fused's boundary hand-over (tests/test_gpu_parity.py): force the pre-pass / shorten the wait
-  if (const char* v = getenv("PINN_T16_PREPASS")) c->t16_prepass = atoi(v) != 0;
-  if (const char* v = getenv("PINN_T16_HANDOVER_TICKS")) c->t16_handover_ticks = atoll(v);
+  // (a value that does not parse is an error, not a silent 0: zero ticks would make every hand-over expire at once)
+  if (const char* v = getenv("PINN_T16_PREPASS")) {
+    if (!(v[0] == '0' || v[0] == '1') || v[1]) { delete c; return fail(PINN_EINVAL, "PINN_T16_PREPASS must be 0 or 1 (got \"%s\")", v); }
+    c->t16_prepass = v[0] == '1';
+    c->t16_prepass_pinned = true;
+  }
+  if (const char* v = getenv("PINN_T16_HANDOVER_TICKS")) {
+    char* end = nullptr;
+    const long long t = strtoll(v, &end, 10);
+    if (end == v || *end || t <= 0) { delete c; return fail(PINN_EINVAL, "PINN_T16_HANDOVER_TICKS must be a positive integer of 100 MHz ticks (got \"%s\")", v); }
+    c->t16_handover_ticks = t;
+  }
   if (const char* v = getenv("PINN_T16_COSTS")) {
     double a = 0, b = 0;
-    if (sscanf(v, "%lf,%lf", &a, &b) == 2 && a > 0 && b > 0) { c->t16_cost_full = a; c->t16_cost_strip = b; }
+    char tail = 0;
+    if (sscanf(v, "%lf,%lf%c", &a, &b, &tail) != 2 || !(a > 0 && b > 0)) { delete c; return fail(PINN_EINVAL, "PINN_T16_COSTS must be two positive numbers \"full,strip\" (got \"%s\")", v); }
+    c->t16_cost_full = a; c->t16_cost_strip = b;
   }
   const size_t n = nd.n_theta;
   if (dev_alloc(&c->theta, n * 8) || dev_alloc(&c->gl, (size_t)c->R * 8) ||
@@ -1224,9 +1260,12 @@ int pinn_destroy(pinn_ctx* c) {
                   c->d_Ast, c->d_A3, c->d_U3, c->d_Nn, c->d_R, c->d_dAp, c->d_lossp, c->d_lamp,
                   c->pred, c->d_ref, c->err_partial, c->err_res, c->d_nonfinite, c->t16_bsync, c->t16_gscr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (c->h_lb_state) (void)hipHostFree(c->h_lb_state);
-  if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
-  if (c->h_lb_log_iter) (void)hipHostFree(c->h_lb_log_iter);
+  for (auto& p : c->pend) {
+    if (p.h_state) (void)hipHostFree(p.h_state);
+    if (p.h_loss) (void)hipHostFree(p.h_loss);
+    if (p.h_iter) (void)hipHostFree(p.h_iter);
+    if (p.ev) (void)hipEventDestroy(p.ev);
+  }
   if (c->h_err) (void)hipHostFree(c->h_err);
   for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
@@ -1366,22 +1405,70 @@ int pinn_adam_init(pinn_ctx* c, double lr, double beta1, double beta2, double ep
   return 0;
 }
 
-int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
+// ---- chunks in flight (see pinn_ctx::Pending) ----------------------------------------------------------------------
+static int pend_outstanding(const pinn_ctx* c) { return (int)(c->tickets_issued - c->tickets_collected); }
+
+// every chunk in flight is waited for and forgotten (its results are dropped): before anything that restarts an optimiser
+static int pend_drain(pinn_ctx* c) {
+  if (pend_outstanding(c) == 0) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->tickets_collected = c->tickets_issued;
+  return 0;
+}
+
+// the slot of the next ticket, with pinned room for n_loss doubles / n_iter ints (+ an L-BFGS state when asked)
+static int pend_reserve(pinn_ctx* c, int kind, size_t n_loss, size_t n_iter, bool want_state, pinn_ctx::Pending** out) {
+  REQUIRE(pend_outstanding(c) < pinn_ctx::N_PENDING, "%d chunks are in flight already: collect the oldest ticket first",
+          pinn_ctx::N_PENDING);
+  pinn_ctx::Pending& p = c->pend[c->tickets_issued % pinn_ctx::N_PENDING];
+  if (!p.ev) HIPCHK(hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+  if (n_loss > p.cap_loss) {
+    if (p.h_loss) (void)hipHostFree(p.h_loss);
+    p.h_loss = nullptr; p.cap_loss = 0;
+    const size_t cap = n_loss < 64 ? 64 : n_loss;
+    HIPCHK(hipHostMalloc((void**)&p.h_loss, cap * 8, hipHostMallocDefault));
+    p.cap_loss = cap;
+  }
+  if (n_iter > p.cap_iter) {
+    if (p.h_iter) (void)hipHostFree(p.h_iter);
+    p.h_iter = nullptr; p.cap_iter = 0;
+    const size_t cap = n_iter < 64 ? 64 : n_iter;
+    HIPCHK(hipHostMalloc((void**)&p.h_iter, cap * 4, hipHostMallocDefault));
+    p.cap_iter = cap;
+  }
+  if (want_state && !p.h_state) HIPCHK(hipHostMalloc((void**)&p.h_state, sizeof(LbfgsState), hipHostMallocDefault));
+  p.kind = kind;
+  *out = &p;
+  return 0;
+}
+
+// n_steps Adam iterations into the stream.  record = false: nothing is kept (pinn_adam_run with losses == NULL).
+static int adam_issue(pinn_ctx* c, int n_steps, bool record, int* ticket) {
   REQUIRE(c && n_steps >= 0, "bad arguments");
   REQUIRE(c->adam_ready, "pinn_adam_init has not been called");
   HIPCHK(hipSetDevice(c->device));
-  if (n_steps == 0) return 0;
   const Range rg("pinn_adam_run");
-  if (losses && (size_t)n_steps > c->cap_loss_hist) {
-    if (dev_alloc(&c->loss_hist, (size_t)n_steps * 3 * 8)) return PINN_EHIP;
-    c->cap_loss_hist = n_steps;
+  pinn_ctx::Pending* p = nullptr;
+  double* region = nullptr;
+  if (record) {
+    if (int rc = pend_reserve(c, 1, (size_t)3 * (n_steps > 0 ? n_steps : 1), 0, false, &p)) return rc;
+    if ((size_t)n_steps > c->cap_loss_hist) {          // a larger ring: nothing may be in flight while it is replaced
+      if (int rc = pend_drain(c)) return rc;
+      if (int rc = pend_reserve(c, 1, (size_t)3 * n_steps, 0, false, &p)) return rc;
+      const size_t cap = n_steps < 16 ? 16 : n_steps;
+      if (dev_alloc(&c->loss_hist, cap * pinn_ctx::N_PENDING * 3 * 8)) return PINN_EHIP;
+      c->cap_loss_hist = cap;
+    }
+    region = c->loss_hist + (size_t)(c->tickets_issued % pinn_ctx::N_PENDING) * c->cap_loss_hist * 3;
+    p->n = n_steps;
+    p->want_terms = c->adam_want_terms;
   }
   const int n = c->nd.n_theta;
   for (int s = 0; s < n_steps; ++s) {
     c->adam_t += 1;
     const double t = (double)c->adam_t;
     const double alpha = c->lr * std::sqrt(1.0 - std::pow(c->b2, t)) / (1.0 - std::pow(c->b1, t));
-    double* slot = losses ? c->loss_hist + (size_t)3 * s : nullptr;
+    double* slot = region ? region + (size_t)3 * s : nullptr;
     if (!c->comm || c->xg.on) {                   // reduction (+ mailbox all-reduce) + update in one kernel
       const AdamFuse af{alpha, slot};
       int rc = eval_loss_grad(c, &af);
@@ -1396,16 +1483,49 @@ int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
       hipLaunchKernelGGL((k_adam<float>), dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->gl, c->theta, (float*)c->theta_r, c->adam_m, c->adam_v, alpha, c->b1, c->b2, c->eps, slot, n, c->nd, c->img);
   }
   HIPCHK(hipGetLastError());
-  if (losses) {
-    std::vector<double> h3((size_t)3 * n_steps);
-    HIPCHK(hipMemcpyAsync(h3.data(), c->loss_hist, h3.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (int rc = xg_check(c)) return rc;        // a lost mailbox peer: the steps after it were not applied
-    if (c->adam_want_terms) memcpy(losses, h3.data(), h3.size() * 8);
-    else for (int s = 0; s < n_steps; ++s) losses[s] = h3[3 * s] + h3[3 * s + 1] + h3[3 * s + 2];
+  if (record) {
+    if (n_steps > 0)
+      HIPCHK(hipMemcpyAsync(p->h_loss, region, (size_t)3 * n_steps * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(p->ev, c->stream));
+    if (ticket) *ticket = (int)(c->tickets_issued & 0x7fffffff);
+    c->tickets_issued += 1;
   }
   return 0;
 }
+
+static int adam_collect(pinn_ctx* c, int ticket, double* losses) {
+  REQUIRE(c, "null");
+  REQUIRE(pend_outstanding(c) > 0 && ticket == (int)(c->tickets_collected & 0x7fffffff),
+          "ticket %d is not the oldest chunk in flight (tickets are collected in the order they were issued)", ticket);
+  pinn_ctx::Pending& p = c->pend[c->tickets_collected % pinn_ctx::N_PENDING];
+  REQUIRE(p.kind == 1, "ticket %d belongs to an L-BFGS chunk", ticket);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventSynchronize(p.ev));
+  c->tickets_collected += 1;
+  if (int rc = xg_check(c)) return rc;          // a lost mailbox peer: the steps after it were not applied
+  if (losses) {
+    if (p.want_terms) memcpy(losses, p.h_loss, (size_t)3 * p.n * 8);
+    else for (int s = 0; s < p.n; ++s) losses[s] = p.h_loss[3 * s] + p.h_loss[3 * s + 1] + p.h_loss[3 * s + 2];
+  }
+  return 0;
+}
+
+int pinn_adam_run(pinn_ctx* c, int n_steps, double* losses) {
+  REQUIRE(c && n_steps >= 0, "bad arguments");
+  if (n_steps == 0) return 0;
+  if (!losses) return adam_issue(c, n_steps, false, nullptr);
+  REQUIRE(pend_outstanding(c) == 0, "pinn_adam_run: %d chunk(s) are in flight; collect them first", pend_outstanding(c));
+  int ticket = 0;
+  if (int rc = adam_issue(c, n_steps, true, &ticket)) return rc;
+  return adam_collect(c, ticket, losses);
+}
+
+int pinn_adam_enqueue(pinn_ctx* c, int n_steps, int* ticket) {
+  REQUIRE(c && ticket && n_steps >= 1, "bad arguments");
+  return adam_issue(c, n_steps, true, ticket);
+}
+
+int pinn_adam_collect(pinn_ctx* c, int ticket, double* losses) { return adam_collect(c, ticket, losses); }
 
 int pinn_adam_run_terms(pinn_ctx* c, int n_steps, double* terms3) {
   REQUIRE(c && terms3, "null");
@@ -1423,7 +1543,8 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
   c->lb_max_iter = max_iter; c->lb_lr = lr; c->lb_ncorr = n_corr;
   c->lb_tol_fun = tol_fun; c->lb_tol_x = tol_x;
   c->lb_max_eval = max_eval > 0 ? max_eval : 1.25 * max_iter;     // custom_lbfgs.py:50
-  c->lb_iters_issued = 0; c->lb_logged_read = 0; c->lb_post_pending = false;
+  if (int rc = pend_drain(c)) return rc;                            // a restart: chunks still in flight are dropped
+  c->lb_iters_issued = 0; c->lb_logged_read = 0; c->lb_issued_at_read = 0; c->lb_post_pending = false;
   c->lb_ready = false;
   if (max_iter == 0) { c->lb_ready = true; return 0; }           // custom_lbfgs.py:43-44
   if (!c->lb_state) {
@@ -1481,26 +1602,30 @@ int pinn_lbfgs_begin(pinn_ctx* c, int max_iter, double lr, int n_corr, double to
     HIPCHK(hipStreamSynchronize(c->stream));
     if (int rc2 = xg_check(c)) return rc2;
   }                                               // otherwise nothing is read back: pinn_lbfgs_run synchronises
-  if (!c->h_lb_state) HIPCHK(hipHostMalloc((void**)&c->h_lb_state, sizeof(LbfgsState), hipHostMallocDefault));
-  if (max_iter + 1 > c->h_lb_cap_log) {
-    if (c->h_lb_log_loss) (void)hipHostFree(c->h_lb_log_loss);
-    if (c->h_lb_log_iter) (void)hipHostFree(c->h_lb_log_iter);
-    c->h_lb_log_loss = nullptr; c->h_lb_log_iter = nullptr; c->h_lb_cap_log = 0;
-    HIPCHK(hipHostMalloc((void**)&c->h_lb_log_loss, (size_t)(max_iter + 1) * 8, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&c->h_lb_log_iter, (size_t)(max_iter + 1) * 4, hipHostMallocDefault));
-    c->h_lb_cap_log = max_iter + 1;
-  }
   c->lb_ready = true;
   return 0;
 }
 
-int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged, int* done) {
+// up to n_iters iterations into the stream, then the state and the window of log entries they can have added on their way
+// to the chunk's pinned buffers
+static int lbfgs_issue(pinn_ctx* c, int n_iters, int* ticket) {
   REQUIRE(c && n_iters >= 0, "bad arguments");
   REQUIRE(c->lb_ready, "pinn_lbfgs_begin has not been called");
   HIPCHK(hipSetDevice(c->device));
   const Range rg("pinn_lbfgs_run");
-  if (n_logged) *n_logged = 0;
-  if (c->lb_max_iter == 0) { if (done) *done = 1; return 0; }
+  pinn_ctx::Pending* p = nullptr;
+  // one log entry per evaluation settled since the host last looked: the iterations issued since then, this chunk's, + 1
+  int window = (c->lb_iters_issued - c->lb_issued_at_read) + n_iters + 1;
+  if (window > c->lb_cap_log - c->lb_logged_read) window = c->lb_cap_log - c->lb_logged_read;
+  if (window < 0 || c->lb_max_iter == 0) window = 0;
+  if (int rc = pend_reserve(c, 2, (size_t)window + 1, (size_t)window + 1, true, &p)) return rc;
+  if (c->lb_max_iter == 0) {                                       // custom_lbfgs.py:43-44: nothing to do, done at once
+    p->n = -1;
+    HIPCHK(hipEventRecord(p->ev, c->stream));
+    if (ticket) *ticket = (int)(c->tickets_issued & 0x7fffffff);
+    c->tickets_issued += 1;
+    return 0;
+  }
   const int n = c->nd.n_theta;
   for (int s = 0; s < n_iters && c->lb_iters_issued < c->lb_max_iter; ++s) {
     c->lb_iters_issued += 1;
@@ -1556,34 +1681,67 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
     c->lb_post_pending = false;
   }
   HIPCHK(hipGetLastError());
-  // state + every log entry this call can have added (one per evaluation settled: at most n_iters + 1), one sync
-  int maybe = c->lb_cap_log - c->lb_logged_read;
-  if (maybe > n_iters + 1) maybe = n_iters + 1;
-  if (!(iters && losses) || maybe < 0) maybe = 0;
-  HIPCHK(hipMemcpyAsync(c->h_lb_state, c->lb_state + c->lb_flip, sizeof(LbfgsState), hipMemcpyDeviceToHost, c->stream));
-  if (maybe > 0) {
-    HIPCHK(hipMemcpyAsync(c->h_lb_log_iter, c->lb_log_iter + c->lb_logged_read, (size_t)maybe * 4,
-                          hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_lb_log_loss, c->lb_log_loss + c->lb_logged_read, (size_t)maybe * 8,
-                          hipMemcpyDeviceToHost, c->stream));
+  p->n = window; p->base = c->lb_logged_read; p->issued_upto = c->lb_iters_issued;
+  HIPCHK(hipMemcpyAsync(p->h_state, c->lb_state + c->lb_flip, sizeof(LbfgsState), hipMemcpyDeviceToHost, c->stream));
+  if (window > 0) {
+    HIPCHK(hipMemcpyAsync(p->h_iter, c->lb_log_iter + p->base, (size_t)window * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(p->h_loss, c->lb_log_loss + p->base, (size_t)window * 8, hipMemcpyDeviceToHost, c->stream));
   }
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipEventRecord(p->ev, c->stream));
+  if (ticket) *ticket = (int)(c->tickets_issued & 0x7fffffff);
+  c->tickets_issued += 1;
+  return 0;
+}
+
+static int lbfgs_collect(pinn_ctx* c, int ticket, int cap, int* iters, double* losses, int* n_logged, int* done) {
+  REQUIRE(c, "null");
+  REQUIRE(pend_outstanding(c) > 0 && ticket == (int)(c->tickets_collected & 0x7fffffff),
+          "ticket %d is not the oldest chunk in flight (tickets are collected in the order they were issued)", ticket);
+  pinn_ctx::Pending& p = c->pend[c->tickets_collected % pinn_ctx::N_PENDING];
+  REQUIRE(p.kind == 2, "ticket %d belongs to an Adam chunk", ticket);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipEventSynchronize(p.ev));
+  c->tickets_collected += 1;
+  if (n_logged) *n_logged = 0;
+  if (p.n < 0) { if (done) *done = 1; return 0; }
   if (int rc2 = xg_check(c)) return rc2;
-  const LbfgsState hs = *c->h_lb_state;
-  const int fresh = hs.n_logged - c->lb_logged_read;
+  const LbfgsState hs = *p.h_state;
+  int fresh = hs.n_logged - c->lb_logged_read;
+  if (fresh < 0) fresh = 0;
+  REQUIRE(!(iters && losses) || fresh <= cap, "pinn_lbfgs_collect: %d log entries are due, the arrays hold %d", fresh, cap);
   if (fresh > 0 && iters && losses) {
-    if (fresh <= maybe) {
-      memcpy(iters, c->h_lb_log_iter, (size_t)fresh * 4);
-      memcpy(losses, c->h_lb_log_loss, (size_t)fresh * 8);
-    } else {                                      // (cannot happen: kept as the general path)
+    const int off = c->lb_logged_read - p.base;       // entries an earlier ticket has handed out already
+    if (off >= 0 && off + fresh <= p.n) {
+      memcpy(iters, p.h_iter + off, (size_t)fresh * 4);
+      memcpy(losses, p.h_loss + off, (size_t)fresh * 8);
+    } else {                                          // (cannot happen: kept as the general path)
       HIPCHK(hipMemcpy(iters, c->lb_log_iter + c->lb_logged_read, (size_t)fresh * 4, hipMemcpyDeviceToHost));
       HIPCHK(hipMemcpy(losses, c->lb_log_loss + c->lb_logged_read, (size_t)fresh * 8, hipMemcpyDeviceToHost));
     }
   }
   c->lb_logged_read = hs.n_logged;
-  if (n_logged) *n_logged = fresh > 0 ? fresh : 0;
+  c->lb_issued_at_read = p.issued_upto;
+  if (n_logged) *n_logged = (iters && losses) ? fresh : 0;
   if (done) *done = hs.done;
   return 0;
+}
+
+int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_logged, int* done) {
+  REQUIRE(c && n_iters >= 0, "bad arguments");
+  REQUIRE(pend_outstanding(c) == 0, "pinn_lbfgs_run: %d chunk(s) are in flight; collect them first", pend_outstanding(c));
+  int ticket = 0;
+  if (int rc = lbfgs_issue(c, n_iters, &ticket)) return rc;
+  return lbfgs_collect(c, ticket, n_iters + 1, iters, losses, n_logged, done);
+}
+
+int pinn_lbfgs_enqueue(pinn_ctx* c, int n_iters, int* ticket) {
+  REQUIRE(c && ticket && n_iters >= 1, "bad arguments");
+  return lbfgs_issue(c, n_iters, ticket);
+}
+
+int pinn_lbfgs_collect(pinn_ctx* c, int ticket, int cap, int* iters, double* losses, int* n_logged, int* done) {
+  REQUIRE(cap >= 0, "bad arguments");
+  return lbfgs_collect(c, ticket, cap, iters, losses, n_logged, done);
 }
 
 int pinn_lbfgs_set_mode(pinn_ctx* c, int mode) {
@@ -1753,6 +1911,7 @@ int pinn_comm_init(pinn_ctx* c, const char* id128, int n_ranks, int rank) {
   memcpy(&id, id128, 128);
   NCCLCHK(ncclCommInitRank(&c->comm, n_ranks, id, rank));
   c->n_ranks = n_ranks; c->rank = rank;
+  t16_prepass_for_ranks(c, n_ranks);
   return 0;
 }
 
@@ -1808,6 +1967,7 @@ int pinn_comm_xgmi_attach(pinn_ctx* c, const char* handles, int n_handles, int* 
   c->xg.grid_cap = c->xg.sharing > 1 ? (c->n_cu / (4 * (c->xg.sharing - 1)) > 8 ? c->n_cu / (4 * (c->xg.sharing - 1)) : 8) : 0;
   if (const char* v = getenv("PINN_XGMI_GRID_CAP")) c->xg.grid_cap = atoi(v);
   c->xg.attached = true;
+  t16_prepass_for_ranks(c, n_handles);
   *mapped_ok = 1;
   return 0;
 }

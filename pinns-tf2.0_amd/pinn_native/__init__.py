@@ -164,6 +164,11 @@ _SIGNATURES = {
                                         ctypes.c_double]),
     "pinn_lbfgs_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p, _c_double_p,
                                       _c_int_p, _c_int_p]),
+    "pinn_adam_enqueue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
+    "pinn_adam_collect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p]),
+    "pinn_lbfgs_enqueue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
+    "pinn_lbfgs_collect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_int_p, _c_double_p,
+                                          _c_int_p, _c_int_p]),
     "pinn_lbfgs_get_x": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
@@ -514,7 +519,47 @@ class Engine(object):
         self._check(self._lib.pinn_adam_run(self._h, int(n_steps), _dp(losses)))
         return losses[:n_steps]
 
+    # -- the same loops with the host one chunk behind the GPU (include/pinn_hip.h: pinn_*_enqueue / _collect) --------
+    MAX_IN_FLIGHT = 4
+
+    def adam_enqueue(self, n_steps):
+        """n_steps Adam iterations into the stream -> ticket (returns at once); adam_collect(ticket) -> their losses"""
+        t = ctypes.c_int(0)
+        self._check(self._lib.pinn_adam_enqueue(self._h, int(n_steps), ctypes.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._tickets[t.value] = int(n_steps)
+        return t.value
+
+    def adam_collect(self, ticket):
+        n = self._tickets[ticket]
+        losses = np.empty(max(n, 1), dtype=np.float64)
+        self._check(self._lib.pinn_adam_collect(self._h, int(ticket), _dp(losses)))
+        del self._tickets[ticket]
+        return losses[:n]
+
+    def lbfgs_enqueue(self, n_iters):
+        t = ctypes.c_int(0)
+        self._check(self._lib.pinn_lbfgs_enqueue(self._h, int(n_iters), ctypes.byref(t)))
+        self._tickets = getattr(self, "_tickets", {})
+        self._lb_uncollected = getattr(self, "_lb_uncollected", 0) + int(n_iters)
+        self._tickets[t.value] = int(n_iters)
+        return t.value
+
+    def lbfgs_collect(self, ticket):
+        """-> (iters, losses, done) of the log entries that became due with this chunk"""
+        cap = self._lb_uncollected + 1            # every iteration enqueued since the last collect may have logged one entry
+        iters = np.zeros(cap, dtype=np.int32)
+        losses = np.zeros(cap, dtype=np.float64)
+        n_logged, done = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self._lib.pinn_lbfgs_collect(self._h, int(ticket), cap, iters.ctypes.data_as(_c_int_p), _dp(losses),
+                                                 ctypes.byref(n_logged), ctypes.byref(done)))
+        del self._tickets[ticket]
+        self._lb_uncollected = sum(self._tickets.values())
+        k = n_logged.value
+        return iters[:k].copy(), losses[:k].copy(), done.value
+
     def lbfgs_begin(self, max_iter, lr, n_corr, tol_fun, tol_x=1e-19, max_eval=0.0):
+        self._tickets, self._lb_uncollected = {}, 0          # chunks still in flight are dropped by the engine (a restart)
         self._lb_max_iter = int(max_iter)
         self._check(self._lib.pinn_lbfgs_begin(self._h, int(max_iter), lr, int(n_corr), tol_fun,
                                                tol_x, max_eval))

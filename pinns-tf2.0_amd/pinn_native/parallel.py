@@ -90,6 +90,33 @@ def attach_shards(engine, world, rank, X_f=None, X_u=None, u=None, X_lb=None, X_
         engine.set_boundary(X_lb[lo:hi], X_ub[lo:hi], n_total=len(X_lb))
 
 
+def _comm_init_bounded(engine, unique_id, world, rank):
+    """engine.comm_init (ncclCommInitRank, a collective) under a deadline -> None on success, else a one-line error.
+    A rank whose peers never arrive (one of them failed before entering the call) would otherwise sit in it until the
+    launcher's watchdog: after PINN_COMM_INIT_TIMEOUT_S (default 180) the rank reports a time-out into the gather that
+    follows, like any other failure.  The call itself cannot be cancelled; it is left behind in a daemon thread and the
+    engine never selects the RCCL mode afterwards."""
+    import threading
+    from . import PinnNativeError
+    limit = float(os.environ.get("PINN_COMM_INIT_TIMEOUT_S", "180"))
+    box = {}
+
+    def run():
+        try:
+            engine.comm_init(unique_id, world, rank)
+            box["err"] = None
+        except PinnNativeError as e:
+            box["err"] = str(e).splitlines()[0][:200]
+        except Exception as e:                                   # anything else is this rank's failure as well
+            box["err"] = "%s: %s" % (type(e).__name__, str(e)[:160])
+    t = threading.Thread(target=run, name="pinn_comm_init", daemon=True)
+    t.start()
+    t.join(limit)
+    if t.is_alive():
+        return "ncclCommInitRank did not return within %.0f s on rank %d (a peer never joined?)" % (limit, rank)
+    return box["err"]
+
+
 def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True, probe=False):
     """Create the communicator of `engine`.
 
@@ -110,11 +137,7 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True, probe=F
     if rccl:
         box = [Engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        try:
-            engine.comm_init(box[0], world, rank)
-            mine = None
-        except PinnNativeError as e:
-            mine = str(e).splitlines()[0][:200]
+        mine = _comm_init_bounded(engine, box[0], world, rank)
         errors = [None] * world
         dist.all_gather_object(errors, mine)
         if any(errors):
@@ -195,4 +218,7 @@ def init_engine_comm(engine, dist, world, rank, mailbox=None, rccl=True, probe=F
     if rccl:
         engine.comm_set_mode("rccl")
         return "rccl"
+    if engine.comm_fallback:
+        raise RuntimeError("no gradient exchange available: %s, and the mailbox all-reduce that was tried in its place is "
+                           "unavailable too (per-rank verdicts %s)" % (engine.comm_fallback, verdicts))
     raise RuntimeError("mailbox all-reduce unavailable and no RCCL communicator requested: %s" % verdicts)

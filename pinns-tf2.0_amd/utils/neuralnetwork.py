@@ -168,6 +168,7 @@ class NeuralNetwork(object):
         # L-BFGS restart guard (nt_optimization): off in the reference's arithmetic, on in float32
         guard = hp.get("nt_guard", 1e3 if self.compute_dtype in ("f32", "float32") else 0.0)
         self._nt_guard = float(guard or 0.0)
+        self._async_log = bool(hp.get("async_log", True))        # log lines one chunk behind the GPU (see _pipelined)
         self.nt_restarts = []
 
     # ---- point sets (sharded over the ranks of a data-parallel launch) ---------------------------
@@ -324,6 +325,8 @@ class NeuralNetwork(object):
         epoch = 0
         n_design = self._n_f_total or self._engine.n_f
         every = self._resample_every if n_design > 0 else 0
+        if self._pipelined() and not every:
+            return self._tf_optimization_pipelined(freq)
         while epoch < self.tf_epochs:
             if every and epoch > 0 and epoch % every == 0:
                 # one design for the whole job; a rank draws its own block of it (counter-based: no communication)
@@ -339,6 +342,36 @@ class NeuralNetwork(object):
                 last = epoch + k == stop - 1     # the weights on the device are those after this epoch
                 self.logger.log_train_epoch(epoch + k, loss_value, self._log_custom() if last else "")
             epoch = stop
+
+    def _pipelined(self):
+        """log lines one chunk behind the GPU (Engine.adam_enqueue / lbfgs_enqueue): the kernels of the next chunk are in
+        the stream while this process formats and prints the previous chunk's lines, so a log line costs the device
+        nothing.  Same chunks, same kernels, same numbers as the synchronous loops.  Off (hp["async_log"] = false, or
+        automatically) when a line needs more than the chunk's losses: subclasses that append text read from the device
+        (_log_custom: the identification scripts' lambdas) or print per evaluation (_adam_chunk: Schrodinger), periodic
+        resampling, the restart guard (it judges a chunk before the next one may start)."""
+        cls = type(self)
+        return (self._async_log and cls._log_custom is NeuralNetwork._log_custom
+                and cls._adam_chunk is NeuralNetwork._adam_chunk and hasattr(self._engine, "adam_enqueue"))
+
+    def _log_boundaries(self, total, freq):
+        """chunk ends: every chunk runs up to and including the next epoch that is logged (0, freq, 2 freq, ...)"""
+        stops, epoch = [], 0
+        while epoch < total:
+            epoch = min(total, (epoch + freq - 1) // freq * freq + 1)
+            stops.append(epoch)
+        return stops
+
+    def _tf_optimization_pipelined(self, freq):
+        eng, start, queue = self._engine, 0, []
+        for stop in self._log_boundaries(self.tf_epochs, freq) + [None]:
+            if stop is not None:
+                queue.append((start, eng.adam_enqueue(stop - start)))
+                start = stop
+            while queue and (stop is None or len(queue) > 1):       # keep ONE chunk ahead of the one being logged
+                first, ticket = queue.pop(0)
+                for k, loss_value in enumerate(eng.adam_collect(ticket)):
+                    self.logger.log_train_epoch(first + k, loss_value, "")
 
     def _adam_chunk(self, n):
         """n device-resident Adam steps; the loss before each update.  Subclasses that print per-evaluation
@@ -376,8 +409,24 @@ class NeuralNetwork(object):
         # untouched (same kernels, same iterates); at most MAX_RESTARTS discards per call.
         # A restart from the SAME boundary as the one before it would be a bit-for-bit replay (same weights, empty
         # history, reproducible kernels -> the same explosion): each repeat at one boundary halves the step length
-        # (learningRate x 0.5^repeats) for that attempt.  A chunk flagged bad is never made the restart point, also
-        # once the restarts are spent.
+        # (learningRate x 0.5^repeats) from there on -- for ALL remaining iterations of the call, not only for the chunk
+        # that failed (the factor is printed with the restart and recorded in nt_restarts).  A chunk flagged bad is never
+        # made the restart point, also once the restarts are spent.
+        if self._nt_guard <= 0 and self._pipelined():
+            # one chunk ahead of the one being logged; a chunk enqueued after the run has ended (its `done` is seen one
+            # chunk late) changes nothing on the device
+            eng, queue, done = self._engine, [], 0
+            while not done:
+                queue.append(eng.lbfgs_enqueue(freq))
+                if len(queue) > 1:
+                    iters, losses, done = eng.lbfgs_collect(queue.pop(0))
+                    for it, loss_value in zip(iters, losses):
+                        self.logger.log_train_epoch(int(it), loss_value, "", True)
+            for ticket in queue:                                   # the chunk(s) that ran ahead: their entries, if any
+                iters, losses, _ = eng.lbfgs_collect(ticket)
+                for it, loss_value in zip(iters, losses):
+                    self.logger.log_train_epoch(int(it), loss_value, "", True)
+            return
         guard, base, restarts, done = self._nt_guard, 0, 0, 0
         last_restart_at, repeats = None, 0
         best = np.inf                                       # lowest loss of an accepted chunk
@@ -395,11 +444,15 @@ class NeuralNetwork(object):
                     restarts += 1
                     repeats = repeats + 1 if last_restart_at == keep_it else 0
                     last_restart_at = keep_it
-                    self.nt_restarts.append((base + int(iters[k]), keep_it))
+                    # (iteration whose loss was refused, iteration restarted from, learningRate factor in force from there
+                    #  to the end of this call -- the reduced step of a repeated restart PERSISTS: going back to the full
+                    #  step would need another lbfgs_begin, i.e. another loss of the curvature history)
+                    self.nt_restarts.append((base + int(iters[k]), keep_it, 0.5 ** repeats))
                     if self.is_root:
                         print("nt_guard: loss %.3e at L-BFGS iteration %d (lowest accepted %.3e): discarded, restarting "
                               "from iteration %d%s" % (float(losses[k]), base + int(iters[k]), best, keep_it,
-                                                       " with learningRate x %g" % 0.5 ** repeats if repeats else ""),
+                                                       " with learningRate x %g for the rest of the run" % 0.5 ** repeats
+                                                       if repeats else ""),
                               file=sys.stderr)
                     self._engine.set_weights(keep_w)
                     base, done = keep_it, 0
@@ -420,6 +473,13 @@ class NeuralNetwork(object):
 
     # ---- driver ----------------------------------------------------------------------------------
     def fit(self, X_u, u):
+        if self._nt_guard > 0 and self.is_root and self.nt_config.maxIter:
+            # one line, on stderr (stdout stays byte-compatible with the reference's log): this run is allowed to depart
+            # from custom_lbfgs.py:159-163 (no line search, a lost run stays lost) at a restart
+            print("note: L-BFGS restart guard on (nt_guard = %g, %s): a chunk whose loss explodes is discarded and L-BFGS "
+                  "restarts from the last accepted iterate -- the reference has no such guard; hp[\"nt_guard\"] = 0 switches "
+                  "it off" % (self._nt_guard, "the float32 default" if self.compute_dtype in ("f32", "float32")
+                             else "set by hp"), file=sys.stderr)
         self.logger.log_train_start(self)
         X_u = self.tensor(X_u)
         u = self.tensor(u)

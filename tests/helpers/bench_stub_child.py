@@ -38,6 +38,7 @@ class StubEngine(object):
     def lbfgs_begin(self, n, *a): self.left = n
     def lbfgs_run(self, n): self.w = self.w - 1e-4 * self.left; return np.zeros(0, np.int32), np.zeros(0), 1
     def sync(self): pass
+    def loss_grad(self, want_grad=True): return 0.28, (np.zeros(self.n_params) if want_grad else None), np.array([0.004, 0.276, 0.0])
     def timing_enable(self, n, every=1): pass
     def timing_read(self): return {"fwd_ms": 0.03, "sweeps_ms": 0.03, "eval_ms": 0.04, "empty_bracket_ms": 0.005, "kernel_exact": True, "n": 32}
     def predict(self, X): return np.zeros((len(X), 1))

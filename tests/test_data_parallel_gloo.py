@@ -90,6 +90,11 @@ class _ScriptedEngine(object):
 
     def comm_init(self, uid, world, rank):
         self.calls.append("comm_init")
+        import time
+        if self.s.get("late") == self.rank:                    # a rank that reaches the collective seconds after the others
+            time.sleep(self.s.get("late_s", 2.0))
+        if self.s.get("rccl_hangs_unless_failing") is not None and self.s.get("rccl_fails") != self.rank:
+            time.sleep(3600)                                   # its peer died before the call: ncclCommInitRank never returns
         if self.s.get("rccl_fails") in ("all", self.rank):
             import pinn_native
             raise pinn_native.PinnNativeError("ncclCommInitRank failed: scripted (rank %d)" % self.rank)
@@ -117,6 +122,8 @@ def _comm_worker(rank, world, port, out_dir, scenario):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if scenario.get("init_timeout_s"):
+        os.environ["PINN_COMM_INIT_TIMEOUT_S"] = str(scenario["init_timeout_s"])
     if scenario.get("policy"):
         os.environ["PINN_COMM"] = scenario["policy"]
     else:
@@ -129,7 +136,7 @@ def _comm_worker(rank, world, port, out_dir, scenario):
     try:
         mode = parallel.init_engine_comm(eng, dist, world, rank)
     except RuntimeError as e:
-        mode = "error:" + str(e)[:40]
+        mode = "error:" + str(e)[:120]
         eng.mode = mode
     with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
         f.write("%s|%s|%s|%s" % (mode, eng.mode, ",".join(eng.calls), getattr(eng, "comm_fallback", None)))
@@ -531,6 +538,57 @@ def test_rccl_failure_on_some_ranks_only_is_an_error_everywhere(tmp_path):
     mp.spawn(_comm_worker, args=(2, port, str(tmp_path), {"rccl_fails": 1}), nprocs=2, join=True)
     outs = [open(tmp_path / ("rank%d.txt" % r)).read().split("|") for r in range(2)]
     assert all(o[0].startswith("error:RCCL communicator: ranks disagree") for o in outs), outs
+
+
+# ---- the driver's world size: 8 ranks (gloo, scripted engines) -- first-contact insurance for `bench.py --gpus 8` ----------------
+@pytest.mark.parametrize("scenario,expect", [
+    ({}, "rccl"),
+    ({"late": 5, "late_s": 3.0}, "rccl"),                                  # one rank reaches ncclCommInitRank 3 s after the rest
+    ({"rccl_fails": "all"}, "mailbox"),                                    # RCCL fails everywhere -> self-tested mailboxes everywhere
+    ({"rccl_fails": "all", "bad_selftest": 6}, "error:no gradient exchange available: rccl failed"),   # ... and they fail too
+    ({"rccl_fails": 3}, "error:RCCL communicator: ranks disagree"),        # one failing rank: an error on all eight
+    # one rank fails BEFORE the collective, the other seven would sit in it for ever: the deadline turns that into a
+    # failure on every rank (unanimous), and the mailboxes take over
+    ({"rccl_fails": 3, "rccl_hangs_unless_failing": True, "init_timeout_s": 3}, "mailbox"),
+])
+def test_comm_setup_is_unanimous_at_world_size_8(tmp_path, scenario, expect):
+    port = 29300 + (os.getpid() + 7 * len(str(scenario))) % 90
+    mp.spawn(_comm_worker, args=(8, port, str(tmp_path), scenario), nprocs=8, join=True)
+    outs = [open(tmp_path / ("rank%d.txt" % r)).read().split("|") for r in range(8)]
+    assert all(o[0].startswith(expect) for o in outs), outs
+    assert len(set(o[1] for o in outs)) == 1 or expect.startswith("error"), outs      # one mode on all eight
+    if scenario.get("init_timeout_s"):
+        assert sum("did not return within 3 s" in o[3] for o in outs) >= 1 or "did not return" in outs[0][3], outs
+
+
+def test_bench_self_launch_eight_ranks_prints_one_contract_line():
+    """the driver's 8-GPU command, with the engine scripted: one JSON line, the metric's 10000 points and cfg 5's 10^6 split
+    eight ways, every leg on an 8-rank communicator"""
+    import json
+    rc, out, err = _self_launch(8, ["--gpus", "8", "--steps", "6", "--warmup", "3"], device_count=lambda: 8)
+    assert rc == 0, err
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and "exited with code" not in err
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["parallelism"] == "dp8"
+    assert j["config"]["n_f_per_gpu"] == 1250 and j["config"]["replicas_identical"] is True
+    assert j["cfg5_leg"]["n_f_per_gpu"] == 125000 and j["cfg5_leg"]["allreduce"] == "rccl"
+    assert j["cfg3_leg"]["n_f_per_gpu"] == 1250 and j["cfg4_leg"]["n_f_per_gpu"] == 2500
+    assert j["launch"] == "bench.py --gpus 8 (self-launched ranks)" and j["cpu_baseline"] is None
+    assert abs(j["value"] - 10000 * 6 / (j["ms_per_step"] * 6e-3)) < 1e-6 * j["value"]
+
+
+def test_bench_self_launch_eight_ranks_one_failing_rank():
+    rc, out, err = _self_launch(8, ["--gpus", "8", "--steps", "6", "--warmup", "3"], env={"BENCH_STUB_FAIL_RANK": "6"},
+                                device_count=lambda: 8)
+    assert rc == 7 and out == "" and "rank 6 of 8 exited with code 7" in err
+
+
+def test_bench_rank_watchdog_at_eight_ranks():
+    rc, out, err = _self_launch(8, ["--gpus", "8", "--steps", "6", "--warmup", "3", "--no-cfg34-legs", "--no-cfg5-leg"],
+                                env={"BENCH_STUB_STALL_RANK": "5", "PINN_BENCH_RANK_TIMEOUT_S": "15"}, device_count=lambda: 8)
+    assert rc == 124 and out == ""
+    assert "of 8 exited with code 124" in err and "did not finish within 15 s" in err
 
 
 def test_fit_refuses_replicas_that_drifted_apart(tmp_path):

@@ -139,7 +139,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(pinn_native.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pinn_abi_version() == 5
+    assert lib.pinn_abi_version() == 6
     # plain C types only in the header
     code = re.sub(r"/\*.*?\*/", "", header, flags=re.S)          # strip comments
     assert "torch" not in code and "std::" not in code and "#include <stdint.h>" in code
@@ -275,6 +275,104 @@ def test_port_fit_log_matches_the_reference_run():
         assert a.split("loss = ")[1].strip() == b.split("loss = ")[1].strip()      # the printed loss
 
 
+# ---- log lines one chunk behind the GPU (NeuralNetwork._pipelined), scripted engine ------------------------------------------
+class _TicketEngine(object):
+    """the enqueue / collect surface: records the ORDER of calls; a chunk's losses are a function of the epoch alone, so the
+    pipelined and the synchronous loops must print the same lines"""
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f64", device=0):
+        self.n_params, self.w, self.calls = 5, np.zeros(5), []
+        self.n_f = self.n_u = self.n_b = 0
+        self.t, self.epoch, self.pending = 0, 0, {}
+        self.lb_total = self.lb_issued = self.lb_logged = 0
+
+    def set_weights(self, w): self.w = np.array(w, dtype=np.float64)
+    def get_weights(self): return self.w.copy()
+    def adam_init(self, *a): pass
+    def set_data(self, X, u, n_total=None): pass
+    def status(self): return 0, 0
+    def _adam(self, n): e = np.arange(self.epoch, self.epoch + n); self.epoch += n; return 1.0 / (1.0 + e)
+    def adam_run(self, n, want_losses=True): self.calls.append(("run", n)); return self._adam(n)
+
+    def adam_enqueue(self, n):
+        self.t += 1; self.calls.append(("enq", self.t, n)); self.pending[self.t] = self._adam(n); return self.t
+
+    def adam_collect(self, t): self.calls.append(("col", t)); return self.pending.pop(t)
+    def lbfgs_begin(self, n, *a): self.lb_total, self.lb_issued, self.lb_logged = n, 0, 0
+
+    def _lb(self, n):                       # iterations 1 .. total-1 are logged (the last one breaks first, custom_lbfgs.py:192)
+        k = min(n, self.lb_total - self.lb_issued)
+        self.lb_issued += k
+        upto = min(self.lb_issued, self.lb_total - 1)
+        its = np.arange(self.lb_logged + 1, upto + 1, dtype=np.int32)
+        self.lb_logged = upto
+        return its, 0.5 / (1.0 + its), int(self.lb_issued >= self.lb_total)
+
+    def lbfgs_run(self, n): self.calls.append(("lrun", n)); return self._lb(n)
+
+    def lbfgs_enqueue(self, n):
+        self.t += 1; self.calls.append(("lenq", self.t, n)); self.pending[self.t] = self._lb(n); return self.t
+
+    def lbfgs_collect(self, t): self.calls.append(("lcol", t)); return self.pending.pop(t)
+
+
+def _ticket_model(monkeypatch, **hp_extra):
+    p = os.path.join(ROOT, "pinns-tf2.0_amd", "utils")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import neuralnetwork
+    from logger import Logger
+    monkeypatch.setattr(neuralnetwork, "Engine", _TicketEngine)
+    hp = dict({"layers": [2, 1], "tf_epochs": 25, "tf_lr": 0.03, "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 34, "nt_lr": 0.8,
+               "nt_ncorr": 50, "log_frequency": 10}, **hp_extra)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        nn = neuralnetwork.NeuralNetwork(hp, Logger(hp), [1.0, 1.0], [-1.0, 0.0])
+        nn.logger.set_error_fn(lambda: 0.5)
+        nn.fit(np.zeros((4, 2)), np.zeros((4, 1)))
+    strip = re.compile(r"elapsed = \S+ \(\+\S+\)")
+    lines = [strip.sub("", l) for l in buf.getvalue().splitlines() if l.startswith(("tf_epoch", "nt_epoch", "Training", "--"))]
+    return nn, lines
+
+
+def test_pipelined_logging_prints_the_synchronous_lines_one_chunk_behind(monkeypatch):
+    sync, want = _ticket_model(monkeypatch, async_log=False)
+    assert [c[0] for c in sync._engine.calls if c[0] in ("enq", "lenq")] == []
+    assert [c for c in sync._engine.calls if c[0] == "run"] == [("run", 1), ("run", 10), ("run", 10), ("run", 4)]
+    nn, got = _ticket_model(monkeypatch)
+    assert got == want and len([l for l in got if l.startswith("tf_epoch")]) == 3 and len([l for l in got if l.startswith("nt_epoch")]) == 3
+    calls = nn._engine.calls
+    # Adam: the same four chunks; chunk k + 1 is in the stream BEFORE chunk k is collected, never more than two in flight
+    assert [c for c in calls if c[0] in ("enq", "col")] == [("enq", 1, 1), ("enq", 2, 10), ("col", 1), ("enq", 3, 10), ("col", 2),
+                                                            ("enq", 4, 4), ("col", 3), ("col", 4)]
+    # L-BFGS: chunks of log_frequency iterations, one ahead; `done` is seen one chunk late and the chunk that ran ahead is collected too
+    lb = [c for c in calls if c[0] in ("lenq", "lcol")]
+    assert lb[:3] == [("lenq", 5, 10), ("lenq", 6, 10), ("lcol", 5)] and lb[-1][0] == "lcol"
+    assert sorted(c[1] for c in lb if c[0] == "lenq") == sorted(c[1] for c in lb if c[0] == "lcol")     # nothing left in flight
+    assert not nn._engine.pending
+
+
+def test_pipelined_logging_steps_aside_for_lines_that_need_the_device(monkeypatch):
+    """the restart guard judges a chunk before the next one may start; a subclass that appends device state to a line
+    (_log_custom) or prints per evaluation (_adam_chunk) needs the weights of exactly that epoch"""
+    nn, _ = _ticket_model(monkeypatch, nt_guard=1e3)
+    assert [c[0] for c in nn._engine.calls if c[0] in ("lenq", "lrun")] == ["lrun"] * 4       # guard on: synchronous L-BFGS
+    assert any(c[0] == "enq" for c in nn._engine.calls)                                        # (Adam is still pipelined)
+    import neuralnetwork
+
+    class Custom(neuralnetwork.NeuralNetwork):
+        def _log_custom(self):
+            return "l1 = 1"
+    from logger import Logger
+    hp = {"layers": [2, 1], "tf_epochs": 12, "tf_lr": 0.03, "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 12, "nt_lr": 0.8,
+          "nt_ncorr": 50, "log_frequency": 10}
+    with contextlib.redirect_stdout(io.StringIO()):
+        nn = Custom(hp, Logger(hp), [1.0, 1.0], [-1.0, 0.0])
+        nn.logger.set_error_fn(lambda: 0.5)
+        nn.fit(np.zeros((4, 2)), np.zeros((4, 1)))
+    assert not any(c[0] in ("enq", "lenq") for c in nn._engine.calls)
+
+
 # ---- the L-BFGS restart guard of NeuralNetwork.nt_optimization (hp["nt_guard"]), scripted engine ---------------------------
 class _GuardEngine(object):
     """lbfgs_run follows a script of per-chunk loss lists; records the calls the guard makes"""
@@ -330,7 +428,7 @@ def test_nt_guard_discards_an_exploding_chunk_and_restarts_from_the_last_accepte
     assert [c for c in calls if c[0] == "begin"] == [("begin", 40), ("begin", 30)]      # 30 iterations were left
     restored = [c[1] for c in calls if c[0] == "set_weights"]
     assert len(restored) == 1 and np.array_equal(restored[0], nn.w_start + 10.0)        # the weights after chunk 1
-    assert nn.nt_restarts == [(13, 10)]
+    assert nn.nt_restarts == [(13, 10, 1.0)]
     assert [int(l.split()[2]) for l in lines] == [10, 20, 30]          # numbering continues; the discarded chunk is not logged
     assert "nt_guard: loss 3.000e+05 at L-BFGS iteration 13" in capsys.readouterr().err
 
@@ -347,9 +445,9 @@ def test_nt_guard_is_off_in_the_reference_arithmetic_and_bounded_when_on(monkeyp
     # a restart from the same boundary would replay the explosion bit for bit -- every repeat halves the step;
     # and once the restarts are spent the exploded chunk is logged (the run is left alone) but never becomes a restart point
     assert np.allclose(nn._engine.lrs, [0.8, 0.8, 0.4, 0.2, 0.1, 0.05])
-    assert all(r[1] == 10 for r in nn.nt_restarts)
+    assert all(r[1] == 10 for r in nn.nt_restarts) and [r[2] for r in nn.nt_restarts] == [1.0, 0.5, 0.25, 0.125, 0.0625]   # the factor is on record
     nn, _ = _guarded_model(monkeypatch, {"dtype": "f64", "nt_guard": 100.0}, [list(np.ones(10)), [200.0] * 10, list(np.ones(10)), list(np.ones(10)), list(np.ones(9))])
-    assert nn.nt_restarts == [(11, 10)]                                # explicit hp key wins over the dtype default
+    assert nn.nt_restarts == [(11, 10, 1.0)]                                # explicit hp key wins over the dtype default
 
 
 def test_t16_fused_launch_plan_deals_every_tile_and_every_row_exactly_once():
