@@ -412,28 +412,39 @@ def pmc_traffic(name, dtype, n_f_total, world, path):
     applies only to the workload, arithmetic, kernel path and point count it was collected on, on one GPU."""
     table = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if world != 1:
-        return None, "the counter passes were collected on one GPU; this run shards the points over %d" % world
+        return None, "the counter passes were collected on one GPU; this run shards the points over %d" % world, None
     try:
         with open(table) as fh:
             entries = json.load(fh)["entries"]
     except Exception as e:
-        return None, "profiles/pmc_traffic.json unreadable: %s" % e
+        return None, "profiles/pmc_traffic.json unreadable: %s" % e, None
     for e in entries:
         if (e["leg"], e["dtype"], e["kernel_path"], e["points"]) == (name, dtype, path, n_f_total):
-            return float(e["traffic_bytes_per_launch"]), "profiles/pmc_traffic.json <- %s" % e["source"]
+            return (float(e["traffic_bytes_per_launch"]), "profiles/pmc_traffic.json <- %s" % e["source"],
+                    e.get("sources_sha256"))
     return None, ("no counter pass was collected for leg %s, %s, kernel path %d, %d points (profiles/pmc_traffic.json)"
-                  % (name, dtype, path, n_f_total))
+                  % (name, dtype, path, n_f_total)), None
 
 
 def with_traffic(leg_dict, world, name=None):
     """attach the PMC traffic (and the HBM rate it implies) to a leg's roofline"""
     rf = leg_dict["roofline"]
     key = name or {"float32": "headline", "float64": "headline"}.get(leg_dict["name"], leg_dict["name"])
-    rf["traffic"], rf["traffic_source"] = pmc_traffic(key, leg_dict["dtype"], leg_dict["n_f_total"], world,
-                                                      leg_dict["kernel_path"])
+    rf["traffic"], rf["traffic_source"], collected_on = pmc_traffic(key, leg_dict["dtype"], leg_dict["n_f_total"], world,
+                                                                    leg_dict["kernel_path"])
     # the counters are NOT read in this run (rocprofv3 --pmc needs its own passes, MI355X_MICROARCH.md): the figure is the
-    # committed pass of the same launch, looked up in profiles/pmc_traffic.json
-    rf["traffic_provenance"] = {"measured_in_run": False, "file": "profiles/pmc_traffic.json" if rf["traffic"] else None}
+    # committed pass of the same launch (profiles/collect_pmc.py), looked up in profiles/pmc_traffic.json.  Every entry
+    # names the digest of the kernel sources of the library it was collected on: library_matches says whether that is
+    # the library this run executes.
+    running = None
+    try:
+        import pinn_native
+        running = pinn_native.library_digest() or pinn_native._source_digest()
+    except Exception:
+        pass
+    rf["traffic_provenance"] = {"measured_in_run": False, "file": "profiles/pmc_traffic.json" if rf["traffic"] else None,
+                                "collected_on_sources_sha256": collected_on, "running_sources_sha256": running,
+                                "library_matches": bool(collected_on and running and collected_on == running)}
     if rf["traffic"] and rf["avg_launch_ms"]:
         rf["hbm_gbps"] = rf["traffic"] / (rf["avg_launch_ms"] * 1e-3) / 1e9
     return leg_dict

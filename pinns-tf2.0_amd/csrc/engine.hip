@@ -1452,9 +1452,10 @@ static int adam_issue(pinn_ctx* c, int n_steps, bool record, int* ticket) {
   double* region = nullptr;
   if (record) {
     if (int rc = pend_reserve(c, 1, (size_t)3 * (n_steps > 0 ? n_steps : 1), 0, false, &p)) return rc;
-    if ((size_t)n_steps > c->cap_loss_hist) {          // a larger ring: nothing may be in flight while it is replaced
-      if (int rc = pend_drain(c)) return rc;
-      if (int rc = pend_reserve(c, 1, (size_t)3 * n_steps, 0, false, &p)) return rc;
+    if ((size_t)n_steps > c->cap_loss_hist) {
+      // a larger ring: the chunks in flight finish first (their copies into the pinned buffers are then complete and the
+      // tickets stay collectable), only then is the device ring replaced
+      if (pend_outstanding(c) > 0) HIPCHK(hipStreamSynchronize(c->stream));
       const size_t cap = n_steps < 16 ? 16 : n_steps;
       if (dev_alloc(&c->loss_hist, cap * pinn_ctx::N_PENDING * 3 * 8)) return PINN_EHIP;
       c->cap_loss_hist = cap;

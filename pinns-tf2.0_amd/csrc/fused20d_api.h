@@ -13,8 +13,13 @@ namespace pinn {
 constexpr int fused20d_blocks(int H) { return 5 + (H - 1) * 30 + 6; }
 // the flat weight vector is brought into LDS by LDS-DMA in whole 1-KiB pieces (128 doubles)
 inline size_t fused20d_weight_doubles(int n_theta) { return ((size_t)n_theta + 127) / 128 * 128; }
+// one-tile launches (workgroups >= tiles) keep no accumulators: every wave parks the UNFOLDED partial blocks of one phase of
+// the reverse sweep (<= 30 blocks x 64 lanes) in a staging area, double buffered, and the workgroup sums them phase by phase
+constexpr int FUSED20D_STAGE_WAVE = 30 * 64;                    // doubles per wave and buffer
+constexpr int FUSED20D_STAGE_BUF = 4 * FUSED20D_STAGE_WAVE;     // doubles per buffer (four waves)
 inline size_t fused20d_lds_bytes(int n_hidden, int n_theta) {
-  return (fused20d_weight_doubles(n_theta) + (size_t)4 * fused20d_blocks(n_hidden) * 16 + 4 * 256) * sizeof(double);   // + loss-part slots
+  const size_t acc = (size_t)4 * fused20d_blocks(n_hidden) * 16, stage = (size_t)2 * FUSED20D_STAGE_BUF;
+  return (fused20d_weight_doubles(n_theta) + (acc > stage ? acc : stage) + 4 * 256) * sizeof(double);   // + loss-part slots
 }
 
 // entry e = 16 * block + 4 * i + j of a wave's block list -> flat parameter index (reference layout), -1 = padding;

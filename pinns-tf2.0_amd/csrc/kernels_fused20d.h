@@ -49,8 +49,23 @@
                                  // one-tile variants only: the tile-loop variants sit at 256 VGPRs and got 1.6 % SLOWER
                                  // (rocprofv3, N_f = 10^6: 1968 -> 2000 us)
 #endif
+#ifndef PINN_ROT_IN_GEMV
+#define PINN_ROT_IN_GEMV 2       // one-tile variants: a reverse layer's 40 lane rotations are issued inside its GEMV, two
+                                 // ds_bpermute per step, and the phase sum's reads travel under it (0: rotations in front of
+                                 // the sum, the sum in front of the GEMV -- profiles/r06_ab_onetile_v3.txt has the A/B)
+#endif
+#ifndef PINN_ROT_LOOP
+#define PINN_ROT_LOOP 0          // the same interleave in the tile-loop variants (experiment)
+#endif
 #ifndef PINN_OPAQUE_TILE_D
 #define PINN_OPAQUE_TILE_D 0
+#endif
+
+// finer timeline inside reverse layer 4 and forward layer 4 (slots 20..30 of the wave's 32), profiling build -DPINN_STAMPS2 only
+#if defined(PINN_STAMPS) && defined(PINN_STAMPS2)
+#define STAMP2(cond, i) do { if (cond) STAMP(i); } while (0)
+#else
+#define STAMP2(cond, i) do { } while (0)
 #endif
 
 namespace pinn {
@@ -157,7 +172,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* const wl = reinterpret_cast<double*>(lds_raw);
   const int nwp = (nd.n_theta + 127) / 128 * 128;
-  double* const gacc_all = wl + nwp;
+  double* const gacc_all = wl + nwp;                  // tile loop: 4 x NBLK x 16 accumulators; one tile: 2 staging buffers
+  double* const lacc_all = gacc_all + (ONE_TILE ? 2 * FUSED20D_STAGE_BUF : 4 * NBLK * 16);
 
   STAMP(0);
   const int tid = threadIdx.x;
@@ -173,9 +189,10 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   const int pr = i4 * FW + s;              /* reverse pattern:  W[4m + i4][4n + s] */                                 \
   const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   /* lane-index rotation by two bits (bpermute address) */ \
   const int ge = s * 4 + i4;               /* this lane's entry (i, j) of a gradient block */                         \
-  double* const lacc = gacc_all + 4 * NBLK * 16 + wave * 256 + lane;       /* [k * 64]: l_res, l_dat, dl0, dl1 */     \
+  double* const lacc = lacc_all + wave * 256 + lane;                        /* [k * 64]: l_res, l_dat, dl0, dl1 */     \
+  const int sput = (s * 4 + i4) * 4 + ((lane >> 2) & 3);   /* one-tile staging slot: entry-major, the four blocks of an entry adjacent */ \
   const double onesA = i4 == 0 ? 1.0 : 0.0;                     /* rotated "ones" in-group: row 0 = 1 (bias gradients) */ \
-  (void)q; (void)pf; (void)pr; (void)rot4; (void)ge; (void)lacc; (void)onesA; (void)s
+  (void)q; (void)pf; (void)pr; (void)rot4; (void)ge; (void)lacc; (void)onesA; (void)s; (void)sput
   PINN_LANE_INDICES(tid & 63);
   double* const gacc = gacc_all + wave * (NBLK * 16);
 
@@ -191,8 +208,13 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
                                      (__attribute__((address_space(3))) void*)(wl + c * 128), 16, 0, 0);
   {
     typedef double d2 __attribute__((ext_vector_type(2)));
-    d2* const z = reinterpret_cast<d2*>(gacc_all);
-    for (int i = tid; i < 2 * NBLK * 16 + 2 * 256; i += 256) z[i] = d2{0.0, 0.0};   // + the loss-part slots behind them
+    if (ONE_TILE) {                                    // the staging buffers are written before they are read: loss parts only
+      d2* const z = reinterpret_cast<d2*>(lacc_all);
+      for (int i = tid; i < 2 * 256; i += 256) z[i] = d2{0.0, 0.0};
+    } else {
+      d2* const z = reinterpret_cast<d2*>(gacc_all);
+      for (int i = tid; i < 2 * NBLK * 16 + 2 * 256; i += 256) z[i] = d2{0.0, 0.0};   // + the loss-part slots behind them
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -212,6 +234,13 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   //  221 instructions instead of ~3000, bit-reproducible over 200 runs, and 14 % SLOWER: 49.8 vs 43.7 us per step.)
 
   STAMP(1);
+#ifdef PINN_STAGGER
+  // experiment: the four waves of a workgroup run the same instruction stream in step and meet at the LDS pipe; wave w starts
+  // w x PINN_STAGGER x 64 cycles late
+  if (wave == 1) __builtin_amdgcn_s_sleep(PINN_STAGGER);
+  if (wave == 2) { __builtin_amdgcn_s_sleep(PINN_STAGGER); __builtin_amdgcn_s_sleep(PINN_STAGGER); }
+  if (wave == 3) { __builtin_amdgcn_s_sleep(PINN_STAGGER); __builtin_amdgcn_s_sleep(PINN_STAGGER); __builtin_amdgcn_s_sleep(PINN_STAGGER); }
+#endif
 
   for (; tile < n_tiles; tile += gridDim.x) {
     // (PINN_OPAQUE_TILE_D, off by default: see the macro)
@@ -219,10 +248,68 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     if (!ONE_TILE && PINN_OPAQUE_TILE_D) asm volatile("" : "+v"(lane_o));
     PINN_LANE_INDICES(lane_o);
     auto grad_fetch = [&](const int blk) { return ONE_TILE ? 0.0 : gacc[blk * 16 + ge]; };
+    // One tile per workgroup: nothing is accumulated, so the four blocks are not folded in registers (2 x 2 DPP moves + 2
+    // adds per block, 1 300 instructions per tile): every lane parks its own partial in the phase's staging buffer
+    // (entry-major: the four blocks of an entry adjacent), and phase_sum adds blocks and waves with the whole workgroup.
+    int phase_first = 0;
+    double* stage_w = gacc_all + wave * FUSED20D_STAGE_WAVE;
     auto grad_store = [&](double D, const double old, const int blk) {
+      if (ONE_TILE) { stage_w[(blk - phase_first) * 64 + sput] = D; return; }
       D += dpp_mov<DPP_ROW_ROR8>(D);
       D += dpp_mov<DPP_ROW_ROR4>(D);
-      gacc[blk * 16 + ge] = ONE_TILE ? D : old + D;
+      gacc[blk * 16 + ge] = old + D;
+    };
+    // entries of a hidden layer's 30 blocks, relative to the layer's first weight: the same for every layer, derived once.
+    // Thread t owns entries t and t + 256 of a phase.
+    int rel_hidden[2] = {-1, -1};
+    if (ONE_TILE) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int e = tid + 256 * k, bl = e >> 4, i = (e >> 2) & 3, j = e & 3;
+        if (bl < 25) { const int m = bl / 5, n = bl - 5 * m; rel_hidden[k] = (4 * m + i) * FW + 4 * n + j; }
+        else if (bl < 30 && i == 0) rel_hidden[k] = FW * FW + 4 * (bl - 25) + j;       // the bias row follows the kernel
+      }
+    }
+    double* __restrict__ const row1 = part + (size_t)blockIdx.x * R;
+    // sum of one phase: all four waves have parked their NB blocks in buffer `buf`; entry e of the phase = 4 waves x 4
+    // blocks in fixed order -> its place in the workgroup's gradient row.  to_index(e) = flat parameter index or -1.
+    //   phase_issue   barrier (all four waves have parked the phase) + the 16 reads of this thread's two entries
+    //   phase_finish  4 waves x 4 blocks added in fixed order, stored at the entry's place in the workgroup's gradient row
+    // Threads without a second entry read a clamped address and store nothing (no divergent branch around the reads).
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 ps_lo[2][4], ps_hi[2][4];
+    auto phase_issue = [&](const int n_entries, const int buf) {
+      __syncthreads();
+      const double* __restrict__ const sb = gacc_all + buf * FUSED20D_STAGE_BUF;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (256 * k >= n_entries) continue;
+        const int e = tid + 256 * k < n_entries ? tid + 256 * k : n_entries - 1;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          ps_lo[k][w] = *reinterpret_cast<const d2*>(sb + w * FUSED20D_STAGE_WAVE + 4 * e);
+          ps_hi[k][w] = *reinterpret_cast<const d2*>(sb + w * FUSED20D_STAGE_WAVE + 4 * e + 2);
+        }
+      }
+    };
+    auto phase_finish = [&](const int n_entries, auto to_index) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (256 * k >= n_entries) continue;
+        const int e = tid + 256 * k;
+        const int idx = e < n_entries ? to_index(e, k) : -1;
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const double t = (ps_lo[k][w].x + ps_lo[k][w].y) + (ps_hi[k][w].x + ps_hi[k][w].y);
+          v = w == 0 ? t : v + t;
+        }
+        if (idx >= 0) row1[idx] = v;
+      }
+    };
+    auto idx_dense_h = [&](const int e, int) {
+      const int m = e >> 4, i = (e >> 2) & 3, j = e & 3;
+      return j != 0 ? -1 : m < 5 ? nd.off_w[H] + 4 * m + i : (i == 0 ? nd.off_b[H] : -1);
     };
     const int pt = tile * 64 + wave * 16 + q;
     const double hx = __builtin_fma(sx, x - lbx, -1.0), ht = __builtin_fma(st, t - lbt, -1.0);
@@ -258,12 +345,18 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       // `ds_read2_b64; s_waitcnt lgkmcnt(0); v_mfma` 259 times per tile (round-4 ISA count) -- and a lone wave then
       // sits out the LDS latency in front of each group of matrix instructions.
       if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
-        double Aq[2] = {wd[0], wd[80]};
+        // (requested in PAIRS -- steps t + 2 and t + 3 at every even t -- so that two patterns travel in one ds_read2_b64:
+        //  13 LDS instructions per GEMV instead of 25)
+        auto fpat = [&](const int t) { return wd[80 * (t % 5) + 4 * (t / 5)]; };
+        double Aq[4] = {fpat(0), fpat(1), 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
           const int n = t / 5, m = t - 5 * n;
-          const double A = Aq[t & 1];
-          if (t + 2 < 25) Aq[t & 1] = wd[80 * ((t + 2) % 5) + 4 * ((t + 2) / 5)];
+          const double A = Aq[t & 3];
+          if ((t & 1) == 0) {
+            if (t + 2 < 25) Aq[(t + 2) & 3] = fpat(t + 2);
+            if (t + 3 < 25) Aq[(t + 3) & 3] = fpat(t + 3);
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c][n] = mfma444(A, in[c][m], acc[c][n]);
@@ -280,6 +373,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           }
         }
       }
+      STAMP2(d == 4, 29);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         const double a = tanh_d(acc[0][n]);
@@ -341,6 +435,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           for (int m = 0; m < 5; ++m) D[m] = mfma444(lane_fetch(in[c][m], rot4), sbT[c], D[m]);
         }
         D[5] = mfma444(onesA, sbT[0], 0.0);
+        phase_first = BLK_H;                                   // phase 0 of the reverse sweep: buffer 0
+        stage_w = gacc_all + wave * FUSED20D_STAGE_WAVE;
 #pragma unroll
         for (int m = 0; m < 6; ++m) grad_store(D[m], old[m], BLK_H + m);
       }
@@ -356,14 +452,49 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     for (int d = H - 1; d >= 1; --d) {
       // pre-activation adjoints of layer d, and their point-major (rotated) copies for the weight gradient
       double zb[4][5], zbT[4][5];
+      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 2)
+        phase_issue(d == H - 1 ? 6 * 16 : 30 * 16, d == H - 1 ? 0 : (H - d - 1) & 1);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
         double a, zp, zq, zr;
         if (d == H - 1) { a = top[n][0]; zp = top[n][1]; zq = top[n][2]; zr = top[n][3]; }
         else { a = agd_get(stash[d][n][0]); zp = agd_get(stash[d][n][1]); zq = agd_get(stash[d][n][2]); zr = agd_get(stash[d][n][3]); }
         preact_adjoint_d(a, zp, zq, zr, ob[0][n], ob[1][n], ob[2][n], ob[3][n], zb[0][n], zb[1][n], zb[2][n], zb[3][n]);
+        if constexpr (!(ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV) && !(!ONE_TILE && PINN_ROT_LOOP)) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) zbT[c][n] = lane_fetch(zb[c][n], rot4);
+          for (int c = 0; c < 4; ++c) zbT[c][n] = lane_fetch(zb[c][n], rot4);
+        }
+      }
+      STAMP2(d == 4, 20);
+      // One tile: the phase before this one is summed HERE, not where its last block was parked -- the stash entries of
+      // layer d, read a first time for that phase's rotated inputs, are still in registers for the adjoints above (a
+      // barrier in between would end their basic block and cost a second v_accvgpr_read each).
+      // The LDS pipe is the second bottleneck of this kernel (a ds_bpermute costs a wave ~31 cycles of it with four waves
+      // on the CU, a ds_read_b128 ~53: profiles/r01_ubench_lds_rates.txt, r06_stamps2_new.txt), and it runs beside the
+      // matrix pipe: the barrier and the 16 reads of the sum go in front of the reverse GEMV, this layer's 40 lane rotations
+      // -- needed only by the weight-gradient blocks behind the GEMV -- are issued two per GEMV step, and the adds and
+      // stores of the sum follow the GEMV.
+      auto finish_prev = [&]() {
+        if (d == H - 1) phase_finish(6 * 16, idx_dense_h);
+        else phase_finish(30 * 16, [&](int, const int k) { return rel_hidden[k] < 0 ? -1 : nd.off_w[d + 1] + rel_hidden[k]; });
+      };
+      if constexpr (ONE_TILE) {
+        if (!(PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 2)) phase_issue(d == H - 1 ? 6 * 16 : 30 * 16, d == H - 1 ? 0 : (H - d - 1) & 1);
+        if (!(PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 1)) finish_prev();
+      }
+      STAMP2(d == 4, 21);
+      // the first in-group's inputs of the weight-gradient blocks: formed here, rotated in the last steps of the GEMV
+      constexpr bool ROT_FIRST = ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV;
+      double cur[4] = {0.0, 0.0, 0.0, 0.0}, first_nat[4] = {0.0, 0.0, 0.0, 0.0};
+      if constexpr (ROT_FIRST) {
+        double a_, zp_, zq_, zr_;
+        if (d - 1 == 0) {
+          a_ = a0[0]; zp_ = sx * wl[nd.off_w[0] + s]; zq_ = st * wl[nd.off_w[0] + FW + s]; zr_ = 0.0;
+        } else {
+          a_ = agd_get(stash[d - 1][0][0]); zp_ = agd_get(stash[d - 1][0][1]);
+          zq_ = agd_get(stash[d - 1][0][2]); zr_ = agd_get(stash[d - 1][0][3]);
+        }
+        channels_d(a_, zp_, zq_, zr_, first_nat[0], first_nat[1], first_nat[2], first_nat[3]);
       }
       // adjoint of the layer-(d-1) outputs: in_bar[4m + i] = sum_j z_bar_j W_d[4m + i][j]
       const double* __restrict__ wd = wl + nd.off_w[d] + pr;
@@ -372,12 +503,18 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         ob[0][m] = ob[1][m] = ob[2][m] = ob[3][m] = 0.0;
       }
       if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
-        double Aq[2] = {wd[0], wd[4]};
+        auto rpat = [&](const int t) { return wd[80 * (t / 5) + 4 * (t % 5)]; };
+        double Aq[4] = {rpat(0), rpat(1), 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
           const int m = t / 5, n = t - 5 * m;
-          const double A = Aq[t & 1];
-          if (t + 2 < 25) Aq[t & 1] = wd[80 * ((t + 2) / 5) + 4 * ((t + 2) % 5)];
+          const double A = Aq[t & 3];
+          if ((t & 1) == 0) {
+            if (t + 2 < 25) Aq[(t + 2) & 3] = rpat(t + 2);
+            if (t + 3 < 25) Aq[(t + 3) & 3] = rpat(t + 3);
+          }
+          if (PINN_ROT_IN_GEMV && t < 20) zbT[t / 5][t % 5] = lane_fetch(zb[t / 5][t % 5], rot4);   // one rotation (two ds_bpermute) per step
+          if (PINN_ROT_IN_GEMV && t >= 20 && t < 24) cur[t - 20] = lane_fetch(first_nat[t - 20], rot4);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
@@ -389,15 +526,25 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
 #pragma unroll
           for (int n = 0; n < 5; ++n) {
             const double A = wd[80 * m + 4 * n];
+            if constexpr (PINN_ROT_LOOP) {           // (tile loop) one rotation per step, pinned between the steps
+              const int t = 5 * m + n;
+              if (t < 20) zbT[t / 5][t % 5] = lane_fetch(zb[t / 5][t % 5], rot4);
+              __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
+            if constexpr (PINN_ROT_LOOP) __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
+      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 1) finish_prev();
+      STAMP2(d == 4, 22);
       // dW_d[4m + i][4n + j]: the A operands are the layer-(d-1) output channels, rotated -- produced one in-group
       // ahead of the matrix instructions that consume them (20 values live instead of 40: the kernel sits at the
       // 256-VGPR limit, and with all of them live hipcc sank the accumulator fetches next to their uses)
       const int base = 5 + (d - 1) * 30;
+      phase_first = base;                                      // phase H - d: buffers alternate
+      stage_w = gacc_all + ((H - d) & 1) * FUSED20D_STAGE_BUF + wave * FUSED20D_STAGE_WAVE;
 #define PINN_ROTATED_INPUTS(M, O4)                                                                          \
   do {                                                                                                      \
     double a_, zp_, zq_, zr_;                                                                               \
@@ -413,8 +560,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     O4[0] = lane_fetch(h_, rot4); O4[1] = lane_fetch(p_, rot4);                                             \
     O4[2] = lane_fetch(q_, rot4); O4[3] = lane_fetch(r_, rot4);                                             \
   } while (0)
-      double cur[4];
-      PINN_ROTATED_INPUTS(0, cur);
+      if constexpr (!ROT_FIRST) PINN_ROTATED_INPUTS(0, cur);
 #pragma unroll
       for (int m = 0; m < 5; ++m) {          // five independent accumulator chains per in-group
         double D[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, old[5], nxt[4] = {0.0, 0.0, 0.0, 0.0};
@@ -430,6 +576,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + m * 5 + n);
 #pragma unroll
         for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+        STAMP2(d == 4, 23 + m);
       }
 #undef PINN_ROTATED_INPUTS
       {
@@ -456,6 +603,10 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
                          ob[2][n], ob[3][n], bh, bp, bq, br);
         bT[0][n] = lane_fetch(bh, rot4); bT[1][n] = lane_fetch(bp, rot4); bT[2][n] = lane_fetch(bq, rot4);
       }
+      if constexpr (ONE_TILE) {                                // layer 1's phase
+        phase_issue(30 * 16, (H - 1) & 1);
+        phase_finish(30 * 16, [&](int, const int k) { return rel_hidden[k] < 0 ? -1 : nd.off_w[1] + rel_hidden[k]; });
+      }
       double D[5], old[5];
 #pragma unroll
       for (int n = 0; n < 5; ++n) old[n] = grad_fetch(n);
@@ -465,8 +616,17 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       for (int n = 0; n < 5; ++n) D[n] = mfma444(Ap, bT[1][n], D[n]);
 #pragma unroll
       for (int n = 0; n < 5; ++n) D[n] = mfma444(Aq, bT[2][n], D[n]);
+      phase_first = 0;                                         // phase H
+      stage_w = gacc_all + (H & 1) * FUSED20D_STAGE_BUF + wave * FUSED20D_STAGE_WAVE;
 #pragma unroll
       for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], n);
+      if constexpr (ONE_TILE) {
+        phase_issue(5 * 16, H & 1);
+        phase_finish(5 * 16, [&](const int e, int) {
+          const int f = 4 * (e >> 4) + (e & 3), i = (e >> 2) & 3;
+          return i == 0 ? nd.off_w[0] + f : i == 1 ? nd.off_w[0] + FW + f : i == 2 ? nd.off_b[0] + f : -1;
+        });
+      }
     }
     if (ONE_TILE) break;
   }
@@ -478,12 +638,12 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     // row_index[e]: flat parameter index of entry e of the block list (-1: padding), built once on the host;
     // fetched first so that its (cold) latency hides under the wave sums and the two barriers  (it does: prefetching
     // the table into LDS with the weights' DMA changed nothing -- Adam step 40.79 vs 40.81 us, same box)
-    constexpr int NE = NBLK * 16, NIT = (NE + 255) / 256;
+    constexpr int NE = NBLK * 16, NIT = ONE_TILE ? 1 : (NE + 255) / 256;   // (one tile: the row was written phase by phase)
     int idx[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = tid + 256 * it;
-      idx[it] = e < NE ? row_index[e] : -1;
+      idx[it] = (!ONE_TILE && e < NE) ? row_index[e] : -1;
     }
     const double t0 = wave_sum(lacc[0]), t1 = wave_sum(lacc[64]);
     const double t2 = PDE == 1 ? wave_sum(lacc[128]) : 0.0, t3 = PDE == 1 ? wave_sum(lacc[192]) : 0.0;
@@ -492,16 +652,20 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     if (lane == 0) { scal[wave * 4 + 0] = t0; scal[wave * 4 + 1] = t1; scal[wave * 4 + 2] = t2; scal[wave * 4 + 3] = t3; }
     __syncthreads();
     double* __restrict__ row = part + (size_t)blockIdx.x * R;
-    double v[NIT];
+    if (!ONE_TILE) {
+      double v[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e = tid + 256 * it;
-      const int ee = e < NE ? e : 0;
-      v[it] = ((gacc_all[ee] + gacc_all[NE + ee]) + gacc_all[2 * NE + ee]) + gacc_all[3 * NE + ee];
+      for (int it = 0; it < NIT; ++it) {
+        const int e = tid + 256 * it;
+        const int ee = e < NE ? e : 0;
+        v[it] = ((gacc_all[ee] + gacc_all[NE + ee]) + gacc_all[2 * NE + ee]) + gacc_all[3 * NE + ee];
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if (idx[it] >= 0) row[idx[it]] = v[it];
+    } else if (blockIdx.x >= n_tiles) {                // (cannot happen: the launch plan gives every workgroup a tile)
+      for (int i = tid; i < nd.n_theta; i += 256) row[i] = 0.0;
     }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      if (idx[it] >= 0) row[idx[it]] = v[it];
     if (tid < 4) {
       const double v = ((scal[tid] + scal[4 + tid]) + scal[8 + tid]) + scal[12 + tid];
       if (tid == 0) { row[nd.n_theta + 0] = v; row[nd.n_theta + 2] = 0.0; }

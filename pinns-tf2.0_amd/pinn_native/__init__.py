@@ -52,6 +52,18 @@ def _source_digest():
     return h.hexdigest()
 
 
+def library_digest(lib=None):
+    """sources-sha256 recorded beside the library when it was built (what the code that RUNS was compiled from); None when
+    the flags file is missing"""
+    try:
+        for line in open((lib or LIB_PATH) + ".flags"):
+            if line.startswith("sources-sha256 "):
+                return line.split()[1]
+    except OSError:
+        pass
+    return None
+
+
 def _stale(lib=None):
     """A library is current when the flags file beside it names these flags AND these source contents (a digest, not
     file times: a snapshot copied to another machine keeps no usable time order).  Without a flags file: file times."""

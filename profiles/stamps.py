@@ -55,6 +55,15 @@ def main():
     for i, nme in enumerate(names):
         print("%-34s %10.0f %10.0f %10.0f" % (nme, np.median(per[:, i]), per[:, i].min(), per[:, i].max()))
     print("%-34s %10.0f" % ("sum of medians", np.median(per, axis=0).sum()))
+    if path == 7:
+        full = eng.debug_stamps().astype(np.float64).reshape(-1, 4, 32)
+        if np.all(full[:, :, 20:28] > 0):                  # -DPINN_STAMPS2: inside reverse layer 4 and forward layer 4
+            def seg(a, b):
+                return np.median((full[:, :, b] - full[:, :, a]).max(axis=1))
+            r0, r1 = 2 * H + 1 - 5, 2 * H + 1 - 4           # end of reverse layer 5 = start of layer 4; its end
+            print("# reverse layer 4: adjoints + rotations %.0f | phase sum (barrier) %.0f | reverse GEMV %.0f | dW in-groups %s | bias blocks %.0f" % (
+                seg(r0, 20), seg(20, 21), seg(21, 22), " ".join("%.0f" % seg(22 + m, 23 + m) for m in range(5)), seg(27, r1)))
+            print("# forward layer 4: GEMV %.0f | tanh + channels + stash %.0f" % (seg(4, 29), seg(29, 5)))
     if path == 7 and st.shape[0] != (n_f + 100 + 63) // 64:         # k_fused20dh: waves 0-2 = mains, wave 3 = helper
         print("# helper-wave variant (48-point tiles): mains (slowest of waves 0-2) | helper wave, medians over workgroups")
         pm, ph = dur[:, :3, :].max(axis=1), dur[:, 3, :]

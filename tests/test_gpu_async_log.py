@@ -79,6 +79,13 @@ def test_ticket_rules(burgers_sets):
         eng.adam_run(1)
     assert all(len(eng.adam_collect(k)) == 2 for k in t)
     assert len(eng.adam_run(3)) == 3
+    # a chunk larger than the loss ring while another one is in flight: the ring grows, the earlier ticket stays collectable
+    ref = _engine(burgers_sets, N_u=64, N_f=2048)
+    ref.adam_run(3 + 8)
+    want = np.concatenate([ref.adam_run(1), ref.adam_run(50)])
+    t1, t2 = eng.adam_enqueue(1), eng.adam_enqueue(50)
+    assert np.array_equal(np.concatenate([eng.adam_collect(t1), eng.adam_collect(t2)]), want)
+    ref.close()
     # a restart drops what is in flight: lbfgs_begin with a chunk outstanding, then a clean run
     eps = float(np.finfo(float).eps)
     eng.lbfgs_begin(12, 0.8, 50, eps)

@@ -622,7 +622,7 @@ def test_fused_f64_sweep_with_the_boundary_forward_prepass(schrodinger_sets, mon
 
 def test_boundary_handover_timeout_is_an_explicit_error_and_the_context_recovers(schrodinger_sets, monkeypatch):
     """VERDICT r4 item 5 / ADVICE r4: a boundary workgroup whose partners are not resident in time must not hand back a
-    silent NaN.  PINN_T16_HANDOVER_TICKS=-1 makes every wait expire at once (the first of the 7 boundary workgroups to
+    silent NaN.  PINN_T16_HANDOVER_TICKS=1 (10 ns; the engine refuses non-positive or unparsable values) makes every wait expire at once (the first of the 7 boundary workgroups to
     arrive cannot have seen the others): the call fails with PINN_ESTATE naming the cause, the context moves to the
     forward pre-pass, and the repeated call gives the hand-over's numbers."""
     from pinn_native import PinnNativeError
@@ -630,7 +630,7 @@ def test_boundary_handover_timeout_is_an_explicit_error_and_the_context_recovers
     eng.set_weights(w)
     want_l, want_g, _ = eng.loss_grad()
     eng.close()
-    monkeypatch.setenv("PINN_T16_HANDOVER_TICKS", "-1")
+    monkeypatch.setenv("PINN_T16_HANDOVER_TICKS", "1")
     eng, w, sets = _schrodinger_engine(schrodinger_sets)
     eng.set_weights(w)
     with pytest.raises(PinnNativeError) as e:
@@ -643,3 +643,8 @@ def test_boundary_handover_timeout_is_an_explicit_error_and_the_context_recovers
     losses = eng.adam_run(3)
     assert np.all(np.isfinite(losses))
     eng.close()
+    # a value that does not parse is an error at pinn_create, not a silent 0 ticks
+    for bad in ("-1", "0", "soon", "12x"):
+        monkeypatch.setenv("PINN_T16_HANDOVER_TICKS", bad)
+        with pytest.raises(PinnNativeError, match="PINN_T16_HANDOVER_TICKS"):
+            _schrodinger_engine(schrodinger_sets)
