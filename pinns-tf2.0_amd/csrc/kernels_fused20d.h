@@ -116,6 +116,21 @@ __device__ __forceinline__ double lane_fetch(const double x, const int src4) {
 
 constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128;
 
+// The weight-gradient blocks contract over POINTS, so both their operands need the point index where the matrix instruction
+// contracts (lane bits 4-5) and the feature slot on bits 0-1.  Rounds 2-5 moved every value there with a ds_bpermute pair
+// (a rotation of the lane index by two bits): 642 of them per tile, ~31 cycles of the LDS pipe each with four waves on the
+// CU -- a quarter of the kernel's time (profiles/r06_stamps2_new.txt).  The matrix instruction itself can do the move: with
+// the 4 x 4 identity as B (lane 16k + 4b + j holds [k == j]),
+//     D[i][j] = sum_k A[i][k] [k == j] = A[i][j]:   lane 16i + 4b + j  <-  lane 16j + 4b + i,
+// i.e. the slot field and the low two point bits of the lane index change places inside every block -- exactly a valid
+// operand layout for the gradient blocks (contraction over the low point bits, one block per high-point-bit value; both
+// operands and the "ones" / (hx, ht, 1) patterns of the bias and first-layer blocks use the same convention).  Products
+// with 1.0 and sums with zeros are exact, so the moved value is bit-identical to the bpermute's.  One instruction of the
+// matrix pipe (16 cycles, no LDS round trip, no address register) instead of two of the LDS pipe.
+#ifndef PINN_ROT_MFMA
+#define PINN_ROT_MFMA 1          // 0: the ds_bpermute pair
+#endif
+
 // tanh(x) = sign(x) (1 - t) / (1 + t), t = e^{-2|x|}: the denominator lies in (1, 2], so the quotient needs none of
 // the scaling / fix-up of an IEEE division: v_rcp_f64 seed + two Newton steps (relative error < 1e-30 before the
 // final rounding), 5 instructions instead of 11.
@@ -175,6 +190,11 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   double* const gacc_all = wl + nwp;                  // tile loop: 4 x NBLK x 16 accumulators; one tile: 2 staging buffers
   double* const lacc_all = gacc_all + (ONE_TILE ? 2 * FUSED20D_STAGE_BUF : 4 * NBLK * 16);
 
+#if PINN_ROT_MFMA
+#define PINN_TO_POINTS(X) mfma444((X), ident, 0.0)
+#else
+#define PINN_TO_POINTS(X) lane_fetch((X), rot4)
+#endif
   STAMP(0);
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -188,11 +208,12 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   const int pf = s * FW + i4;              /* forward pattern:  W[4m + s][4n + i4] */                                 \
   const int pr = i4 * FW + s;              /* reverse pattern:  W[4m + i4][4n + s] */                                 \
   const int rot4 = (((lane >> 2) | (lane << 4)) & 63) << 2;   /* lane-index rotation by two bits (bpermute address) */ \
+  const double ident = s == i4 ? 1.0 : 0.0;                    /* 4 x 4 identity as a B operand: the transposing matrix instruction */ \
   const int ge = s * 4 + i4;               /* this lane's entry (i, j) of a gradient block */                         \
   double* const lacc = lacc_all + wave * 256 + lane;                        /* [k * 64]: l_res, l_dat, dl0, dl1 */     \
   const int sput = (s * 4 + i4) * 4 + ((lane >> 2) & 3);   /* one-tile staging slot: entry-major, the four blocks of an entry adjacent */ \
   const double onesA = i4 == 0 ? 1.0 : 0.0;                     /* rotated "ones" in-group: row 0 = 1 (bias gradients) */ \
-  (void)q; (void)pf; (void)pr; (void)rot4; (void)ge; (void)lacc; (void)onesA; (void)s; (void)sput
+  (void)q; (void)pf; (void)pr; (void)rot4; (void)ident; (void)ge; (void)lacc; (void)onesA; (void)s; (void)sput
   PINN_LANE_INDICES(tid & 63);
   double* const gacc = gacc_all + wave * (NBLK * 16);
 
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     {  // dense H (linear, one output): z_bar = sb.  dW_H[k] = sum IN_c[k] sb_c, db_H = sum sb_h
       double sbT[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) sbT[c] = lane_fetch(s == 0 ? sb[c] : 0.0, rot4);     // column 0 only
+      for (int c = 0; c < 4; ++c) sbT[c] = PINN_TO_POINTS(s == 0 ? sb[c] : 0.0);     // column 0 only
       {
         double D[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, old[6];
 #pragma unroll
@@ -432,7 +453,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-          for (int m = 0; m < 5; ++m) D[m] = mfma444(lane_fetch(in[c][m], rot4), sbT[c], D[m]);
+          for (int m = 0; m < 5; ++m) D[m] = mfma444(PINN_TO_POINTS(in[c][m]), sbT[c], D[m]);
         }
         D[5] = mfma444(onesA, sbT[0], 0.0);
         phase_first = BLK_H;                                   // phase 0 of the reverse sweep: buffer 0
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         preact_adjoint_d(a, zp, zq, zr, ob[0][n], ob[1][n], ob[2][n], ob[3][n], zb[0][n], zb[1][n], zb[2][n], zb[3][n]);
         if constexpr (!(ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV) && !(!ONE_TILE && PINN_ROT_LOOP)) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) zbT[c][n] = lane_fetch(zb[c][n], rot4);
+          for (int c = 0; c < 4; ++c) zbT[c][n] = PINN_TO_POINTS(zb[c][n]);
         }
       }
       STAMP2(d == 4, 20);
@@ -513,8 +534,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
             if (t + 2 < 25) Aq[(t + 2) & 3] = rpat(t + 2);
             if (t + 3 < 25) Aq[(t + 3) & 3] = rpat(t + 3);
           }
-          if (PINN_ROT_IN_GEMV && t < 20) zbT[t / 5][t % 5] = lane_fetch(zb[t / 5][t % 5], rot4);   // one rotation (two ds_bpermute) per step
-          if (PINN_ROT_IN_GEMV && t >= 20 && t < 24) cur[t - 20] = lane_fetch(first_nat[t - 20], rot4);
+          if (PINN_ROT_IN_GEMV && t < 20) zbT[t / 5][t % 5] = PINN_TO_POINTS(zb[t / 5][t % 5]);   // one rotation (two ds_bpermute) per step
+          if (PINN_ROT_IN_GEMV && t >= 20 && t < 24) cur[t - 20] = PINN_TO_POINTS(first_nat[t - 20]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
@@ -528,7 +549,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
             const double A = wd[80 * m + 4 * n];
             if constexpr (PINN_ROT_LOOP) {           // (tile loop) one rotation per step, pinned between the steps
               const int t = 5 * m + n;
-              if (t < 20) zbT[t / 5][t % 5] = lane_fetch(zb[t / 5][t % 5], rot4);
+              if (t < 20) zbT[t / 5][t % 5] = PINN_TO_POINTS(zb[t / 5][t % 5]);
               __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -557,8 +578,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     }                                                                                                       \
     double h_, p_, q_, r_;                                                                                  \
     channels_d(a_, zp_, zq_, zr_, h_, p_, q_, r_);                                                          \
-    O4[0] = lane_fetch(h_, rot4); O4[1] = lane_fetch(p_, rot4);                                             \
-    O4[2] = lane_fetch(q_, rot4); O4[3] = lane_fetch(r_, rot4);                                             \
+    O4[0] = PINN_TO_POINTS(h_); O4[1] = PINN_TO_POINTS(p_);                                             \
+    O4[2] = PINN_TO_POINTS(q_); O4[3] = PINN_TO_POINTS(r_);                                             \
   } while (0)
       if constexpr (!ROT_FIRST) PINN_ROTATED_INPUTS(0, cur);
 #pragma unroll
@@ -591,7 +612,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       STAMP(2 * H + 1 - d);
     }
     {  // dense 0: inputs (hx, ht, 1) in channel h, (sx, 0, 0) in channel p, (0, st, 0) in channel q
-      const double hxT = lane_fetch(hx, rot4), htT = lane_fetch(ht, rot4);
+      const double hxT = PINN_TO_POINTS(hx), htT = PINN_TO_POINTS(ht);
       const double Ah = i4 == 0 ? hxT : i4 == 1 ? htT : i4 == 2 ? 1.0 : 0.0;
       const double Ap = i4 == 0 ? sx : 0.0, Aq = i4 == 1 ? st : 0.0;
       double bT[3][5];
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         double bh, bp, bq, br;
         preact_adjoint_d(a0[n], sx * wl[nd.off_w[0] + f], st * wl[nd.off_w[0] + FW + f], 0.0, ob[0][n], ob[1][n],
                          ob[2][n], ob[3][n], bh, bp, bq, br);
-        bT[0][n] = lane_fetch(bh, rot4); bT[1][n] = lane_fetch(bp, rot4); bT[2][n] = lane_fetch(bq, rot4);
+        bT[0][n] = PINN_TO_POINTS(bh); bT[1][n] = PINN_TO_POINTS(bp); bT[2][n] = PINN_TO_POINTS(bq);
       }
       if constexpr (ONE_TILE) {                                // layer 1's phase
         phase_issue(30 * 16, (H - 1) & 1);
@@ -632,6 +653,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   }
   STAMP(2 * H + 1);
 #undef PINN_LANE_INDICES
+#undef PINN_TO_POINTS
 
   // -------------------------------------------------------------------- one gradient row per workgroup
   {
