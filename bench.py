@@ -775,6 +775,12 @@ def main():
             # which HIP runtime / RCCL build this process bound (pinn_native._bind_runtime: /opt/rocm in a plain process,
             # torch's bundled set in a rank that needs torch.distributed) and how the ranks were started
             "runtime": runtime_record(),
+            # a scaling series mixes runtimes under the default policy: a rank of N > 1 binds the ROCm 7.0 set
+            # bundled with torch (it needs torch.distributed), a plain N = 1 process binds /opt/rocm (7.2).  Measured
+            # difference at N = 1: 0.14 % (profiles/r05_bench_a_*_runtime.json); PINN_HIP_RUNTIME=torch puts N = 1 on the
+            # ranks' runtime, and this key says which policy this line ran under
+            "runtime_policy": {"PINN_HIP_RUNTIME": os.environ.get("PINN_HIP_RUNTIME", "auto"),
+                               "same_runtime_as_multi_rank_runs": (runtime_record().get("bound") == "torch")},
             "launch": ("single process" if world == 1 else "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ
                        else "bench.py --gpus %d (self-launched ranks)" % world),
             ("float32_leg" if other == "f32" else "float64_leg"): other_leg,
