@@ -54,6 +54,12 @@
                                  // ds_bpermute per step, and the phase sum's reads travel under it (0: rotations in front of
                                  // the sum, the sum in front of the GEMV -- profiles/r06_ab_onetile_v3.txt has the A/B)
 #endif
+#ifndef PINN_PA_LOOP
+#define PINN_PA_LOOP 0           // the pinned GEMV loops in the tile-loop variants too (experiment)
+#endif
+#ifndef PINN_ROW_NT
+#define PINN_ROW_NT 0
+#endif
 #ifndef PINN_ROT_LOOP
 #define PINN_ROT_LOOP 0          // the same interleave in the tile-loop variants (experiment)
 #endif
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
   constexpr W20Desc nd_const = w20_desc(H, PDE == 1);
   const W20Desc nd = ONE_TILE ? nd_const : nd_arg;
   constexpr int NBLK = fused20d_blocks(H);
+  constexpr bool PA = PINN_PATTERN_AHEAD && (ONE_TILE || PINN_PA_LOOP);   // the pinned GEMV loops (patterns two steps ahead)
   constexpr int BLK_H = 5 + (H - 1) * 30;            // first block of dense H
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   double* const wl = reinterpret_cast<double*>(lds_raw);
@@ -325,7 +332,13 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           const double t = (ps_lo[k][w].x + ps_lo[k][w].y) + (ps_hi[k][w].x + ps_hi[k][w].y);
           v = w == 0 ? t : v + t;
         }
-        if (idx >= 0) row1[idx] = v;
+        if (idx >= 0) {
+#if PINN_ROW_NT
+          __builtin_nontemporal_store(v, &row1[idx]);      // experiment: the row streams past the L2 (no write-back at kernel end)
+#else
+          row1[idx] = v;
+#endif
+        }
       }
     };
     auto idx_dense_h = [&](const int e, int) {
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       // consume them (sched_barrier pins the order).  Left to itself hipcc sinks every ds_read next to its consumer --
       // `ds_read2_b64; s_waitcnt lgkmcnt(0); v_mfma` 259 times per tile (round-4 ISA count) -- and a lone wave then
       // sits out the LDS latency in front of each group of matrix instructions.
-      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
+      if constexpr (PA) {
         // (requested in PAIRS -- steps t + 2 and t + 3 at every even t -- so that two patterns travel in one ds_read2_b64:
         //  13 LDS instructions per GEMV instead of 25)
         auto fpat = [&](const int t) { return wd[80 * (t % 5) + 4 * (t / 5)]; };
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     for (int d = H - 1; d >= 1; --d) {
       // pre-activation adjoints of layer d, and their point-major (rotated) copies for the weight gradient
       double zb[4][5], zbT[4][5];
-      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 2)
+      if constexpr (ONE_TILE && PA && PINN_ROT_IN_GEMV == 2)
         phase_issue(d == H - 1 ? 6 * 16 : 30 * 16, d == H - 1 ? 0 : (H - d - 1) & 1);
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
@@ -481,7 +494,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         if (d == H - 1) { a = top[n][0]; zp = top[n][1]; zq = top[n][2]; zr = top[n][3]; }
         else { a = agd_get(stash[d][n][0]); zp = agd_get(stash[d][n][1]); zq = agd_get(stash[d][n][2]); zr = agd_get(stash[d][n][3]); }
         preact_adjoint_d(a, zp, zq, zr, ob[0][n], ob[1][n], ob[2][n], ob[3][n], zb[0][n], zb[1][n], zb[2][n], zb[3][n]);
-        if constexpr (!(ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV) && !(!ONE_TILE && PINN_ROT_LOOP)) {
+        if constexpr (!(PA && PINN_ROT_IN_GEMV) && !(!ONE_TILE && PINN_ROT_LOOP)) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) zbT[c][n] = PINN_TO_POINTS(zb[c][n]);
         }
@@ -500,12 +513,12 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         else phase_finish(30 * 16, [&](int, const int k) { return rel_hidden[k] < 0 ? -1 : nd.off_w[d + 1] + rel_hidden[k]; });
       };
       if constexpr (ONE_TILE) {
-        if (!(PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 2)) phase_issue(d == H - 1 ? 6 * 16 : 30 * 16, d == H - 1 ? 0 : (H - d - 1) & 1);
-        if (!(PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 1)) finish_prev();
+        if (!(PA && PINN_ROT_IN_GEMV == 2)) phase_issue(d == H - 1 ? 6 * 16 : 30 * 16, d == H - 1 ? 0 : (H - d - 1) & 1);
+        if (!(PA && PINN_ROT_IN_GEMV == 1)) finish_prev();
       }
       STAMP2(d == 4, 21);
       // the first in-group's inputs of the weight-gradient blocks: formed here, rotated in the last steps of the GEMV
-      constexpr bool ROT_FIRST = ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV;
+      constexpr bool ROT_FIRST = PA && PINN_ROT_IN_GEMV;
       double cur[4] = {0.0, 0.0, 0.0, 0.0}, first_nat[4] = {0.0, 0.0, 0.0, 0.0};
       if constexpr (ROT_FIRST) {
         double a_, zp_, zq_, zr_;
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       for (int m = 0; m < 5; ++m) {
         ob[0][m] = ob[1][m] = ob[2][m] = ob[3][m] = 0.0;
       }
-      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD) {
+      if constexpr (PA) {
         auto rpat = [&](const int t) { return wd[80 * (t / 5) + 4 * (t % 5)]; };
         double Aq[4] = {rpat(0), rpat(1), 0.0, 0.0};
 #pragma unroll
@@ -558,7 +571,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           }
         }
       }
-      if constexpr (ONE_TILE && PINN_PATTERN_AHEAD && PINN_ROT_IN_GEMV == 1) finish_prev();
+      if constexpr (ONE_TILE && PA && PINN_ROT_IN_GEMV == 1) finish_prev();
       STAMP2(d == 4, 22);
       // dW_d[4m + i][4n + j]: the A operands are the layer-(d-1) output channels, rotated -- produced one in-group
       // ahead of the matrix instructions that consume them (20 values live instead of 40: the kernel sits at the

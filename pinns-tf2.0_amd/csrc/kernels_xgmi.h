@@ -58,6 +58,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
                                                              double eps, double* __restrict__ loss3, NetDesc nd,
                                                              float* __restrict__ img, TileScratch ts = TileScratch{}) {
   __shared__ double sh[RED_SLICES][RED_COLS];
+  // the peers' mailbox pointers are indexed by a run-time rank: as a by-value kernel argument that indexing sent the whole
+  // table through scratch (18 spilled registers, 76 B per lane until round 5).  Copied once into LDS with compile-time
+  // indices, read from there with the run-time one: no scratch.
+  __shared__ xg_line_t* sbox[XG_MAX_RANKS];
+#pragma unroll
+  for (int r = 0; r < XG_MAX_RANKS; ++r)
+    if (threadIdx.x == (unsigned)r) sbox[r] = px.box[r];
+  __syncthreads();
   const int q = threadIdx.x >> 6, n_cb = (R + RED_COLS - 1) / RED_COLS;
   const int par = (int)(seq & 1u), nr = px.n_ranks, me = px.rank;
   // One column block per workgroup normally (grid = n_cb).  When several ranks SHARE one device (single-GPU tests) the
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
       const xg_line_t line = {(unsigned int)bits, seq, (unsigned int)(bits >> 32), seq};
       for (int k = 1; k < nr; ++k) {            // start with the next rank: spreads the traffic over the links
         const int r = (me + k) % nr;
-        xg_store(px.box[r] + (size_t)(par * nr + me) * px.Rp + c, line);
+        xg_store(sbox[r] + (size_t)(par * nr + me) * px.Rp + c, line);
       }
     }
     double tot = 0;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) limit = 0;
     for (int r = 0; r < nr; ++r) {
       if (r == me) { tot += g; continue; }
-      const xg_line_t* src = px.box[me] + (size_t)(par * nr + r) * px.Rp + c;
+      const xg_line_t* src = sbox[me] + (size_t)(par * nr + r) * px.Rp + c;
       xg_line_t line = xg_load(src);
       while (line.y != seq || line.w != seq) {
         if (wall_clock64() - t0 > limit) { atomicExch(err, 1); lost = true; break; }
@@ -114,23 +122,30 @@ __global__ __launch_bounds__(RED_THREADS) void k_reduce_xgmi(const real* __restr
   const int n_blocks = n_cb + (ts.gscr ? SLOT_SPLIT * ts.n_slots : 0);   // column blocks, then the half slots of k_t16_fused's scratch
   for (int cb = blockIdx.x; cb < n_blocks; cb += gridDim.x) {
     if (cb != (int)blockIdx.x) __syncthreads();           // sh of the previous block has been consumed
+    // the columns this thread finishes: four of a scratch slot or one of a column block -- ONE copy of the exchange below
+    // (inlined once per call site it spilled 18-21 registers to scratch under the 128-register bound of 1024 threads)
+    int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
     if (cb >= n_cb) {
       double tot4[4];
       int e, L;
       reduce_slot(ts, n_rows, cb - n_cb, sh, tot4, e, L);
-      if (threadIdx.x >= 64 / SLOT_SPLIT) continue;
-#pragma unroll
-      for (int comp = 0; comp < 4; ++comp) {
-        const int c = ts.column(e, L, comp);
-        if (c >= 0) exchange(c, tot4[comp]);
+      if (threadIdx.x < 64 / SLOT_SPLIT) {
+        c0 = ts.column(e, L, 0); c1 = ts.column(e, L, 1); c2 = ts.column(e, L, 2); c3 = ts.column(e, L, 3);
+        g0 = tot4[0]; g1 = tot4[1]; g2 = tot4[2]; g3 = tot4[3];
       }
-      continue;
+    } else {
+      const int c = cb * RED_COLS + (threadIdx.x & 63);
+      const bool skip = ts.backed(c);
+      const double g = reduce_column(part, n_rows, R, skip ? R : c, q, sh);
+      if (q == 0 && c < R && !skip) { c0 = c; g0 = g; }
     }
-    const int c = cb * RED_COLS + (threadIdx.x & 63);
-    const bool skip = ts.backed(c);
-    const double g = reduce_column(part, n_rows, R, skip ? R : c, q, sh);
-    if (q != 0 || c >= R || skip) continue;
-    exchange(c, g);
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const int c = k == 0 ? c0 : k == 1 ? c1 : k == 2 ? c2 : c3;
+      const double g = k == 0 ? g0 : k == 1 ? g1 : k == 2 ? g2 : g3;
+      if (c >= 0) exchange(c, g);
+    }
   }
 }
 

@@ -51,3 +51,34 @@ def test_no_hidden_hazard_in_the_built_library():
     # the walk saw what it is meant to judge: the AGPR stash of the width-20 kernels and the LDS-DMA of the float32 ones
     assert n > 50 and seen["mfma"] > 10000 and seen["v_accvgpr_write_b32"] > 1000 and seen["lds_dma"] > 20, (n, seen)
     assert bad == [], "\n".join(bad[:20])
+
+
+@needs_tools
+def test_no_scratch_in_the_kernels_that_serve_the_baseline_configs_or_the_exchange():
+    """Code-object metadata of the built library (llvm-readelf --notes): the loss+gradient kernels of BASELINE configs[1..4],
+    the reduction / optimiser kernels behind them and -- since round 6 -- every variant of k_reduce_xgmi (the fallback exchange
+    when RCCL fails everywhere; it carried 18 spilled registers until round 5) use no private segment and spill nothing."""
+    import re
+    import subprocess
+    import tempfile
+    import pinn_native
+    readelf = os.path.join(os.path.dirname(isa_lint.OBJDUMP), "llvm-readelf")
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not here")
+    pinn_native.build()
+    wanted = ("k_reduce_xgmi", "k_fused20dILi0ELi8", "k_fused20dILi1ELi8", "k_fused20mILi0ELi8", "k_fused20mILi1ELi8",
+              "k_t16_fusedILi2ELi4", "k_reduce_adam", "k_reduce_rows", "k_lbc_dots", "k_lbc_coef_apply")
+    seen = {}
+    for _, obj in isa_lint.code_objects(pinn_native.LIB_PATH):
+        with tempfile.NamedTemporaryFile(suffix=".o") as fh:
+            fh.write(obj)
+            fh.flush()
+            notes = subprocess.run([readelf, "--notes", fh.name], check=True, capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            if any(w in name for w in wanted):
+                seen[name] = (int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)),
+                              int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1)))
+    assert sum("k_reduce_xgmi" in n for n in seen) == 4 and any("k_t16_fusedILi2ELi4" in n for n in seen), sorted(seen)
+    bad = {n: v for n, v in seen.items() if v != (0, 0)}
+    assert not bad, bad
