@@ -55,10 +55,8 @@
                                  // the sum, the sum in front of the GEMV -- profiles/r06_ab_onetile_v3.txt has the A/B)
 #endif
 #ifndef PINN_PA_LOOP
-#define PINN_PA_LOOP 0           // the pinned GEMV loops in the tile-loop variants too (experiment)
-#endif
-#ifndef PINN_ROW_NT
-#define PINN_ROW_NT 0
+#define PINN_PA_LOOP 1           // the pinned GEMV loops in the tile-loop variants too: N_f = 10^6 1868 -> 1851 us, same box
+                                 // (profiles/r06_ab_loopvariants.txt; with the ds_bpermute rotations of rounds 2-5 this was a loss)
 #endif
 #ifndef PINN_ROT_LOOP
 #define PINN_ROT_LOOP 0          // the same interleave in the tile-loop variants (experiment)
@@ -332,13 +330,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
           const double t = (ps_lo[k][w].x + ps_lo[k][w].y) + (ps_hi[k][w].x + ps_hi[k][w].y);
           v = w == 0 ? t : v + t;
         }
-        if (idx >= 0) {
-#if PINN_ROW_NT
-          __builtin_nontemporal_store(v, &row1[idx]);      // experiment: the row streams past the L2 (no write-back at kernel end)
-#else
-          row1[idx] = v;
-#endif
-        }
+        if (idx >= 0) row1[idx] = v;     // (as a nontemporal store -- the row streaming past the L2 -- the Adam step was 0.6 us
+                                         //  LONGER, profiles/r06_ab_loopvariants.txt)
       }
     };
     auto idx_dense_h = [&](const int e, int) {
