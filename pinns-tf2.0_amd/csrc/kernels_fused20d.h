@@ -11,26 +11,30 @@
 // Taylor channel for the five groups of four features (feature = 4n + s), and a layer is
 //     out_c[n] += W-pattern[m][n] (A)  x  in_c[m] (B)            25 instructions per channel, 20 = 5 x 4: no padding
 // whose result registers ARE the next layer's B operands: lane = (slot, point) in, lane = (slot, point) out, for the
-// forward GEMV and (with the transposed pattern) for the reverse GEMV.  No LDS exchange tile, no barrier, no
+// forward GEMV and (with the transposed pattern) for the reverse GEMV.  No LDS exchange tile and no
 // cross-lane traffic in either sweep; tanh and the Taylor / adjoint algebra are lane-local.  The weight patterns
 // are plain ds_read_b64 of the flat weight vector (copied into LDS once per workgroup): lane (s, i = lane & 3) reads
 // W[4m+s][4n+i] (forward) or W[4m+i][4n+s] (reverse) -- conflict-free, no packed image needed.
 //
 // The weight gradient dW_d[k][j] = sum over (point, channel) IN_c[k] ZBAR_c[j] contracts over POINTS, so both
-// operands need the point index where the instruction contracts (lane bits 4-5) and the feature slot on bits 0-1:
-// a rotation of the lane index by two bits, one ds_bpermute pair per value (40 values per layer).  The four blocks
-// then hold partial sums over the points with q & 3 = b; they are folded with two DPP row rotations and added into a
-// per-wave accumulator in LDS (the accumulators of a wave: 221 blocks x 16 values = 28 KB, persistent over the
-// workgroup's tiles; summed over the four waves in fixed order at the end -> one gradient row per workgroup, no
-// atomics, bit-reproducible).  First and last dense layer run through the same block machinery (in-group
-// (h_x, h_t, 1) / single output column), so there is no per-lane gradient bookkeeping at all.
+// operands need point bits where the instruction contracts (lane bits 4-5) and the feature slot on bits 0-1.  Since
+// round 6 that move is ONE matrix instruction with the 4 x 4 identity as B -- it swaps the slot field with the two LOW
+// point bits (PINN_TO_POINTS below; rounds 2-5: a ds_bpermute pair per value, 642 per tile on the LDS pipe), 40 values
+// per layer.  The four blocks then hold partial sums over the points with the same HIGH point bits.
+//   tile loop (more tiles than workgroups): the blocks are folded with two DPP row rotations and added into a per-wave
+//     accumulator in LDS (221 blocks x 16 values = 28 KB per wave, persistent over the workgroup's tiles; summed over the
+//     four waves in fixed order at the end);
+//   one tile per workgroup: nothing is accumulated -- every lane parks its partial in a double-buffered staging area and
+//     the whole workgroup adds the 4 waves x 4 blocks of every entry once per reverse layer, straight into the gradient row.
+// Either way one gradient row per workgroup, no atomics, bit-reproducible.  First and last dense layer run through the
+// same block machinery (in-group (h_x, h_t, 1) / single output column), so there is no per-lane gradient bookkeeping.
 //
 // Stash: (a, z_x, z_t, z_xx) of the 5 own features x 6 middle layers = 240 registers parked in AGPRs; layer 0 keeps
 // only a (its other channels are weight constants), the last hidden layer stays live in VGPRs.  One wave per SIMD,
 // four waves = 64 points per workgroup, persistent over tiles (grid = min(tiles, CUs)).
 //
-// Work per 64-point tile and hidden layer: 100 (forward) + 100 (reverse GEMV) + 105 (dW) instructions per wave =
-// 5.0k cycles of matrix pipe; algorithmic FLOP and bytes as k_fused20m (68 640 FLOP and 16 B per collocation point).
+// Work per 64-point tile and hidden layer: 100 (forward) + 100 (reverse GEMV) + 105 (dW) + 40 (operand moves) matrix
+// instructions per wave = 5.6k cycles of matrix pipe (305 of them algorithmic); algorithmic FLOP and bytes as k_fused20m (68 640 FLOP and 16 B per collocation point).
 //
 // Math: SURVEY.md Appendix A.1-A.3 == nested GradientTapes of 1d-burgers/inf_cont_burgers.py:65-90 under the outer
 // tape of utils/neuralnetwork.py:55-59; identification (PDE == 1): 1d-burgers/ide_cont_burgers.py:56-91.
@@ -43,23 +47,21 @@
 // k_wide_bwd / k_t16_fused).  Here it takes the tile-loop variants from 256 VGPRs + 6-11 AGPR spill slots to 238-242 / 0
 // and is 1 % SLOWER (same-box A/B, N_f = 10^6: 1991 / 2000 vs 1971 / 1978 us per Adam step): off.
 #ifndef PINN_PATTERN_AHEAD
-#define PINN_PATTERN_AHEAD 1     // weight patterns of the two GEMVs requested two steps ahead (0: hipcc's placement):
-                                 // same-box A/B 40.81 / 40.84 -> 40.57 / 40.50 us per Adam step at N_f = 10^4 -- the LDS
-                                 // latency in front of the matrix instructions was mostly covered already; kept for the
-                                 // one-tile variants only: the tile-loop variants sit at 256 VGPRs and got 1.6 % SLOWER
-                                 // (rocprofv3, N_f = 10^6: 1968 -> 2000 us)
+#define PINN_PATTERN_AHEAD 1     // the GEMV loops pinned step by step (sched_barrier), weight patterns requested in pairs two
+                                 // steps ahead (0: hipcc's placement -- it sinks every ds_read next to its consumer).  Round 4:
+                                 // 40.8 -> 40.5 us per Adam step at N_f = 10^4, and 1.6 % SLOWER in the tile-loop variants
+                                 // (PINN_PA_LOOP below turned that round 6)
 #endif
 #ifndef PINN_ROT_IN_GEMV
-#define PINN_ROT_IN_GEMV 2       // one-tile variants: a reverse layer's 40 lane rotations are issued inside its GEMV, two
-                                 // ds_bpermute per step, and the phase sum's reads travel under it (0: rotations in front of
-                                 // the sum, the sum in front of the GEMV -- profiles/r06_ab_onetile_v3.txt has the A/B)
+#define PINN_ROT_IN_GEMV 2       // where a reverse layer's 40 operand moves (PINN_TO_POINTS) and the one-tile phase sum stand:
+                                 //  0  moves in front of the sum, the whole sum in front of the GEMV
+                                 //  1  moves inside the GEMV (one per pinned step), barrier + reads in front of it, adds behind
+                                 //  2  as 1, barrier + reads in front of the adjoint arithmetic (pure VALU) as well
+                                 // same-box: 36.9 / 35.6 / 35.0 us with the ds_bpermute moves (profiles/r06_ab_onetile_v3, _v4)
 #endif
 #ifndef PINN_PA_LOOP
 #define PINN_PA_LOOP 1           // the pinned GEMV loops in the tile-loop variants too: N_f = 10^6 1868 -> 1851 us, same box
                                  // (profiles/r06_ab_loopvariants.txt; with the ds_bpermute rotations of rounds 2-5 this was a loss)
-#endif
-#ifndef PINN_ROT_LOOP
-#define PINN_ROT_LOOP 0          // the same interleave in the tile-loop variants (experiment)
 #endif
 #ifndef PINN_OPAQUE_TILE_D
 #define PINN_OPAQUE_TILE_D 0
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         if (d == H - 1) { a = top[n][0]; zp = top[n][1]; zq = top[n][2]; zr = top[n][3]; }
         else { a = agd_get(stash[d][n][0]); zp = agd_get(stash[d][n][1]); zq = agd_get(stash[d][n][2]); zr = agd_get(stash[d][n][3]); }
         preact_adjoint_d(a, zp, zq, zr, ob[0][n], ob[1][n], ob[2][n], ob[3][n], zb[0][n], zb[1][n], zb[2][n], zb[3][n]);
-        if constexpr (!(PA && PINN_ROT_IN_GEMV) && !(!ONE_TILE && PINN_ROT_LOOP)) {
+        if constexpr (!(PA && PINN_ROT_IN_GEMV)) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) zbT[c][n] = PINN_TO_POINTS(zb[c][n]);
         }
@@ -553,14 +555,8 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
 #pragma unroll
           for (int n = 0; n < 5; ++n) {
             const double A = wd[80 * m + 4 * n];
-            if constexpr (PINN_ROT_LOOP) {           // (tile loop) one rotation per step, pinned between the steps
-              const int t = 5 * m + n;
-              if (t < 20) zbT[t / 5][t % 5] = PINN_TO_POINTS(zb[t / 5][t % 5]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) ob[c][m] = mfma444(A, zb[c][n], ob[c][m]);
-            if constexpr (PINN_ROT_LOOP) __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
