@@ -16,5 +16,5 @@ cd $R
 DB=$(find gpurun_out/prof_bench -name "*_results.db" | head -1)
 python profiles/summarize_rocpd.py $DB > gpurun_out/r06_bench_kernel_stats.txt 2>&1
 rm -rf gpurun_out/prof_bench
-timeout 1500 python profiles/collect_pmc.py --round r06 > gpurun_out/r06_collect_pmc.log 2>&1
+timeout 2400 python profiles/collect_pmc.py --round r06 --legs headline:f64,headline:f32,cfg3:f64,cfg5:f64,cfg4:f64,cfg3:f32,cfg5:f32,cfg4:f32 > gpurun_out/r06_collect_pmc.log 2>&1
 tail -3 gpurun_out/r06_pytest_gpu.log; tail -2 gpurun_out/r06_smoke.log; head -12 gpurun_out/r06_bench_kernel_stats.txt; tail -5 gpurun_out/r06_collect_pmc.log | cut -c1-300
