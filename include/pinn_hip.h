@@ -48,7 +48,8 @@ enum {
 const char* pinn_last_error(void);
 int pinn_abi_version(void);   /* 2: + discrete-time models, device LHS, mailbox all-reduce, kernel paths 3..6; 3: + pinn_residual_at;
                                  4: + pinn_error_l2, pinn_get_status; 5: + pinn_runtime_versions, pinn_debug_t16_deal;
-                                 6: + pinn_adam_enqueue / _collect, pinn_lbfgs_enqueue / _collect */
+                                 6: + pinn_adam_enqueue / _collect, pinn_lbfgs_enqueue / _collect,
+                                    pinn_weights_snapshot / _restore */
 int pinn_device_count(int* n);
 /* HIP runtime / driver (hipRuntimeGetVersion, hipDriverGetVersion) and RCCL (ncclGetVersion) this process bound; any
  * pointer may be NULL.  No device is touched. */
@@ -142,6 +143,11 @@ int pinn_adam_enqueue(pinn_ctx* c, int n_steps, int* ticket);
 int pinn_adam_collect(pinn_ctx* c, int ticket, double* losses);
 int pinn_lbfgs_enqueue(pinn_ctx* c, int n_iters, int* ticket);
 int pinn_lbfgs_collect(pinn_ctx* c, int ticket, int cap, int* iters, double* losses, int* n_logged, int* done);
+/* Device-side copies of the flat weight vector taken / put back in stream order (slots 0..3; ABI v6): what a caller that
+ * judges a chunk one chunk late (the restart guard of NeuralNetwork.nt_optimization; the reference has neither) returns to
+ * without a host round trip.  pinn_weights_restore also refreshes the compute-dtype mirror, like pinn_set_weights. */
+int pinn_weights_snapshot(pinn_ctx* c, int slot);
+int pinn_weights_restore(pinn_ctx* c, int slot);
 /* 0: one-workgroup kernel performing the two-loop recursion in the reference's operation order;
  * 1 (default, history <= 61): compact form -- all dot products of an iteration in one parallel
  * kernel, recursion on the Gram matrices.  Same mathematics; rounding differs at 1e-16. */

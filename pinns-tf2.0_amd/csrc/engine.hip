@@ -167,6 +167,9 @@ struct pinn_ctx {
     int* h_iter = nullptr; size_t cap_iter = 0;         // pinned
     LbfgsState* h_state = nullptr;                      // pinned
   };
+  static constexpr int N_SNAP = 4;     // pinn_weights_snapshot / _restore slots
+  double* snap = nullptr;
+  unsigned snap_valid = 0;
   static constexpr int N_PENDING = 4;
   Pending pend[N_PENDING];
   unsigned long long tickets_issued = 0, tickets_collected = 0;
@@ -1253,7 +1256,7 @@ int pinn_destroy(pinn_ctx* c) {
   if (c->comm) ncclCommDestroy(c->comm);
   xg_release(c);
   void* ptrs[] = {c->xs, c->ts, c->tgt, c->theta, c->gl, c->adam_m, c->adam_v, c->theta_r, c->S,
-                  c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist,
+                  c->O, c->ZA, c->ZB, c->part, c->xe, c->te, c->Oe, c->f_out, c->loss_hist, c->snap,
                   c->lb_state, c->lb_x, c->lb_d, c->lb_gold, c->lb_S, c->lb_Y, c->lb_ro, c->lb_al,
                   c->lb_q, c->lb_log_loss, c->lb_log_iter, c->lb_SY, c->lb_YY, c->lb_dots, c->lb_cs,
                   c->lb_cy, c->lb_ex, c->img, c->row_index, c->d_ginfo, c->d_M[0], c->d_M[1], c->d_MT[0], c->d_MT[1],
@@ -1361,6 +1364,29 @@ int pinn_set_weights(pinn_ctx* c, const double* w, int64_t n) {
   int rc = cast_weights(c);
   if (rc) return rc;
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->xg.poisoned = false;
+  return 0;
+}
+
+// Device-side copies of the weight vector, in stream order: what the restart guard of NeuralNetwork.nt_optimization goes back
+// to.  Nothing crosses the bus and nothing synchronises, so a snapshot can be taken behind every chunk of iterations that is
+// still in flight.
+int pinn_weights_snapshot(pinn_ctx* c, int slot) {
+  REQUIRE(c && slot >= 0 && slot < pinn_ctx::N_SNAP, "snapshot slot %d outside 0..%d", slot, pinn_ctx::N_SNAP - 1);
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bytes = (size_t)c->nd.n_theta * 8;
+  if (!c->snap && dev_alloc(&c->snap, bytes * pinn_ctx::N_SNAP)) return PINN_EHIP;
+  HIPCHK(hipMemcpyAsync(c->snap + (size_t)slot * c->nd.n_theta, c->theta, bytes, hipMemcpyDeviceToDevice, c->stream));
+  c->snap_valid |= 1u << slot;
+  return 0;
+}
+
+int pinn_weights_restore(pinn_ctx* c, int slot) {
+  REQUIRE(c && slot >= 0 && slot < pinn_ctx::N_SNAP, "snapshot slot %d outside 0..%d", slot, pinn_ctx::N_SNAP - 1);
+  REQUIRE(c->snap && (c->snap_valid >> slot & 1u), "no snapshot in slot %d", slot);
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpyAsync(c->theta, c->snap + (size_t)slot * c->nd.n_theta, (size_t)c->nd.n_theta * 8, hipMemcpyDeviceToDevice, c->stream));
+  if (int rc = cast_weights(c)) return rc;           // the compute-dtype mirror and the LDS image follow, as in pinn_set_weights
   c->xg.poisoned = false;
   return 0;
 }

@@ -181,6 +181,8 @@ _SIGNATURES = {
     "pinn_lbfgs_enqueue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
     "pinn_lbfgs_collect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_int_p, _c_double_p,
                                           _c_int_p, _c_int_p]),
+    "pinn_weights_snapshot": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "pinn_weights_restore": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_lbfgs_get_x": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64]),
     "pinn_lbfgs_set_mode": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "pinn_predict": (ctypes.c_int, [ctypes.c_void_p, _c_double_p, ctypes.c_int64, _c_double_p]),
@@ -569,6 +571,15 @@ class Engine(object):
         self._lb_uncollected = sum(self._tickets.values())
         k = n_logged.value
         return iters[:k].copy(), losses[:k].copy(), done.value
+
+    N_SNAPSHOTS = 4
+
+    def weights_snapshot(self, slot):
+        """device-side copy of the weights into slot 0..3, in stream order (no synchronisation)"""
+        self._check(self._lib.pinn_weights_snapshot(self._h, int(slot)))
+
+    def weights_restore(self, slot):
+        self._check(self._lib.pinn_weights_restore(self._h, int(slot)))
 
     def lbfgs_begin(self, max_iter, lr, n_corr, tol_fun, tol_x=1e-19, max_eval=0.0):
         self._tickets, self._lb_uncollected = {}, 0          # chunks still in flight are dropped by the engine (a restart)

@@ -349,7 +349,7 @@ class NeuralNetwork(object):
         nothing.  Same chunks, same kernels, same numbers as the synchronous loops.  Off (hp["async_log"] = false, or
         automatically) when a line needs more than the chunk's losses: subclasses that append text read from the device
         (_log_custom: the identification scripts' lambdas) or print per evaluation (_adam_chunk: Schrodinger), periodic
-        resampling, the restart guard (it judges a chunk before the next one may start)."""
+        resampling.  The restart guard goes along: its way back is a device-side snapshot behind every chunk."""
         cls = type(self)
         return (self._async_log and cls._log_custom is NeuralNetwork._log_custom
                 and cls._adam_chunk is NeuralNetwork._adam_chunk and hasattr(self._engine, "adam_enqueue"))
@@ -412,27 +412,42 @@ class NeuralNetwork(object):
         # (learningRate x 0.5^repeats) from there on -- for ALL remaining iterations of the call, not only for the chunk
         # that failed (the factor is printed with the restart and recorded in nt_restarts).  A chunk flagged bad is never
         # made the restart point, also once the restarts are spent.
-        if self._nt_guard <= 0 and self._pipelined():
-            # one chunk ahead of the one being logged; a chunk enqueued after the run has ended (its `done` is seen one
-            # chunk late) changes nothing on the device
-            eng, queue, done = self._engine, [], 0
-            while not done:
-                queue.append(eng.lbfgs_enqueue(freq))
-                if len(queue) > 1:
-                    iters, losses, done = eng.lbfgs_collect(queue.pop(0))
-                    for it, loss_value in zip(iters, losses):
-                        self.logger.log_train_epoch(int(it), loss_value, "", True)
-            for ticket in queue:                                   # the chunk(s) that ran ahead: their entries, if any
-                iters, losses, _ = eng.lbfgs_collect(ticket)
-                for it, loss_value in zip(iters, losses):
-                    self.logger.log_train_epoch(int(it), loss_value, "", True)
-            return
+        # Chunks of log_frequency iterations.  Pipelined (see _pipelined): the host stays ONE chunk behind the GPU -- chunk
+        # k + 1 is in the stream while chunk k is judged and logged; `done` is seen one chunk late, and a chunk enqueued after
+        # the run has ended changes nothing on the device.  With the guard on, the point to go back to is a device-side
+        # snapshot taken in stream order behind every chunk (Engine.weights_snapshot: no host round trip), and a chunk that is
+        # judged bad takes the chunk that ran ahead of it down with it.  Synchronous otherwise (the scripted engines of the
+        # CPU tests, subclasses whose lines read device state): same decisions, the restart point a host copy.
+        eng = self._engine
+        pipe = self._pipelined() and (self._nt_guard <= 0 or hasattr(eng, "weights_snapshot"))
         guard, base, restarts, done = self._nt_guard, 0, 0, 0
         last_restart_at, repeats = None, 0
         best = np.inf                                       # lowest loss of an accepted chunk
-        keep_w, keep_it = (self._engine.get_weights(), 0) if guard > 0 else (None, 0)
+        keep, keep_it = None, 0                             # restart point: a snapshot slot (pipelined) or a host copy
+        if guard > 0:
+            if pipe:
+                eng.weights_snapshot(0)
+                keep = 0
+            else:
+                keep = eng.get_weights()
+        queue = []                                          # pipelined: (ticket, snapshot slot behind that chunk) in flight
+
+        def free_slot():
+            used = {keep} | {s for _, s in queue}
+            return next(s for s in range(eng.N_SNAPSHOTS) if s not in used)
+
         while not done:
-            iters, losses, done = self._engine.lbfgs_run(freq)
+            if pipe:
+                while len(queue) < 2:
+                    slot = free_slot() if guard > 0 else -1
+                    ticket = eng.lbfgs_enqueue(freq)
+                    if guard > 0:
+                        eng.weights_snapshot(slot)
+                    queue.append((ticket, slot))
+                ticket, after = queue.pop(0)
+                iters, losses, done = eng.lbfgs_collect(ticket)
+            else:
+                iters, losses, done = eng.lbfgs_run(freq)
             if guard > 0 and len(losses):
                 if not np.isfinite(best):
                     if not np.isfinite(losses[0]):          # already lost before L-BFGS started: nothing to go back to
@@ -454,7 +469,11 @@ class NeuralNetwork(object):
                                                        " with learningRate x %g for the rest of the run" % 0.5 ** repeats
                                                        if repeats else ""),
                               file=sys.stderr)
-                    self._engine.set_weights(keep_w)
+                    if pipe:
+                        eng.weights_restore(keep)
+                        queue = []                          # (lbfgs_begin drops the chunk that ran ahead)
+                    else:
+                        eng.set_weights(keep)
                     base, done = keep_it, 0
                     begin(cfg.maxIter - base, 0.5 ** repeats)
                     continue
@@ -463,7 +482,11 @@ class NeuralNetwork(object):
                 self.logger.log_train_epoch(base + int(it), loss_value, custom, True)
             if guard > 0 and len(iters) and not done and not bad.any():
                 best = min(best, float(np.min(losses)))
-                keep_w, keep_it = self._engine.get_weights(), base + int(iters[-1])
+                keep, keep_it = (after if pipe else eng.get_weights()), base + int(iters[-1])
+        for ticket, _ in queue:                             # the chunk(s) that ran ahead of the end: their entries, if any
+            iters, losses, _ = eng.lbfgs_collect(ticket)
+            for it, loss_value in zip(iters, losses):
+                self.logger.log_train_epoch(base + int(it), loss_value, "", True)
 
     def nt_optimization_steps(self, loss_and_flat_grad):
         """Host-driven variant with the reference's signature: any closure w -> (loss, grad)."""

@@ -125,3 +125,57 @@ def test_fit_logs_one_chunk_behind_and_ends_at_the_same_weights(burgers_sets, mo
         pinn._engine.close()
     assert out[True][0] == out[False][0] and len(out[True][0]) == 10 + 19          # every printed digit of every line
     assert np.array_equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+
+
+def test_weight_snapshots_are_device_side_copies(burgers_sets):
+    eng = _engine(burgers_sets, N_u=64, N_f=2048)
+    w0 = eng.get_weights()
+    eng.weights_snapshot(2)
+    eng.adam_run(5)
+    w5 = eng.get_weights()
+    eng.weights_snapshot(0)
+    assert not np.array_equal(w0, w5)
+    eng.weights_restore(2)
+    assert np.array_equal(eng.get_weights(), w0)
+    l_a = eng.loss_grad()[0]                                # the compute-dtype mirror followed the restore
+    eng.set_weights(w0)
+    assert eng.loss_grad()[0] == l_a
+    eng.weights_restore(0)
+    assert np.array_equal(eng.get_weights(), w5)
+    from pinn_native import PinnNativeError
+    with pytest.raises(PinnNativeError, match="no snapshot in slot 3"):
+        eng.weights_restore(3)
+    with pytest.raises(PinnNativeError, match="outside 0..3"):
+        eng.weights_snapshot(4)
+    eng.close()
+
+
+@pytest.mark.parametrize("guard", [1e3, 0.5])
+def test_guarded_fit_one_chunk_behind_equals_the_synchronous_guard(burgers_sets, monkeypatch, guard):
+    """float32 with the restart guard (its default 1e3 -- no restart on this schedule -- and an absurd 0.5 that refuses every
+    chunk whose loss has not halved, i.e. spends all five restarts at once, each with a halved step): the pipelined loop (device-side snapshots) takes the decisions of the synchronous one
+    (host copies): same restarts, same lines, bit-identical final weights"""
+    import importlib
+    import sys
+    import neuralnetwork
+    monkeypatch.setattr(sys, "argv", ["inf_cont_burgers.py"])
+    mod = importlib.import_module("inf_cont_burgers")
+    r = burgers_sets(100, 10000)
+    X_star, u_star, X_u, u, X_f, ub, lb = r[5], r[6], r[7], r[8], r[9], r[10], r[11]
+    out = {}
+    for mode in (True, False):
+        hp = dict(mod.hp, dtype="f32", async_log=mode, nt_guard=guard, nt_epochs=120)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            neuralnetwork.set_seed(1234)
+            logger = mod.Logger(hp)
+            pinn = mod.BurgersInformedNN(hp, logger, X_f, ub, lb, nu=NU)
+            logger.set_error_fn(lambda: pinn.error_l2(X_star, u_star))
+            pinn.fit(X_u, u)
+        rows = [(m.group(1), int(m.group(2)), m.group(3)) for m in map(LINE.match, buf.getvalue().splitlines()) if m]
+        out[mode] = (rows, pinn.get_weights(), list(pinn.nt_restarts))
+        pinn._engine.close()
+    assert out[True][2] == out[False][2]
+    assert (len(out[True][2]) > 0) == (guard < 2)                   # the hair trigger fires, the default does not
+    assert out[True][0] == out[False][0]
+    assert np.array_equal(out[True][1], out[False][1])

@@ -373,6 +373,80 @@ def test_pipelined_logging_steps_aside_for_lines_that_need_the_device(monkeypatc
     assert not any(c[0] in ("enq", "lenq") for c in nn._engine.calls)
 
 
+class _StatefulEngine(object):
+    """a deterministic model of the engine for the restart guard: the loss of an iteration is a function of (how many times
+    L-BFGS was begun, global iteration number) -- it explodes where EXPLODE says -- and the 'weights' are the global iteration
+    reached.  With snapshot = True it offers the ticketed loops and device-side snapshots, otherwise only the synchronous calls."""
+    EXPLODE = {(1, 13): 3e5, (1, 14): 1e9, (2, 27): float("nan")}       # begin #1 explodes at iteration 13, begin #2 at 27
+
+    def __init__(self, layers, lb, ub, pde="burgers", dtype="f32", device=0):
+        self.n_params, self.pos, self.calls = 5, 0, []
+        self.n_f = self.n_u = self.n_b = 0
+        self.begins, self.base, self.left, self.t, self.pending, self.snaps = 0, 0, 0, 0, {}, {}
+
+    def set_weights(self, w): self.pos = int(round(np.asarray(w, dtype=np.float64).ravel()[0])); self.calls.append(("set", self.pos))
+    def get_weights(self): self.calls.append(("get", self.pos)); return np.full(5, float(self.pos))
+    def adam_init(self, *a): pass
+    def set_data(self, X, u, n_total=None): pass
+    def status(self): return 0, 0
+    def lbfgs_begin(self, n, *a): self.begins += 1; self.base, self.left, self.pending = self.pos, n, {}; self.calls.append(("begin", n))
+
+    def _chunk(self, n):
+        k = min(n, self.left)
+        self.left -= k
+        last = self.pos + k - (1 if self.left == 0 else 0)               # the last iteration breaks before it logs
+        its = np.arange(self.pos + 1, last + 1)
+        losses = np.array([self.EXPLODE.get((self.begins, int(i)), 1.0 / (1.0 + i)) for i in its])
+        self.pos += k
+        return (its - self.base).astype(np.int32), losses, int(self.left == 0)
+
+    def lbfgs_run(self, n): self.calls.append(("run", n)); return self._chunk(n)
+
+
+class _StatefulTicketEngine(_StatefulEngine):
+    N_SNAPSHOTS = 4
+    def lbfgs_enqueue(self, n): self.t += 1; self.pending[self.t] = self._chunk(n); self.calls.append(("enq", self.t)); return self.t
+    def lbfgs_collect(self, t): self.calls.append(("col", t)); return self.pending.pop(t)
+    def adam_enqueue(self, n): raise AssertionError("no Adam in this test")
+    def adam_collect(self, t): raise AssertionError("no Adam in this test")
+    def weights_snapshot(self, slot): self.snaps[slot] = self.pos; self.calls.append(("snap", slot, self.pos))
+    def weights_restore(self, slot): self.pos = self.snaps[slot]; self.calls.append(("restore", slot, self.pos))
+
+
+def test_restart_guard_one_chunk_behind_takes_the_synchronous_decisions(monkeypatch):
+    """round 6: with the guard on, nt_optimization stays one chunk behind the GPU as well -- its way back is a device-side
+    snapshot behind every chunk instead of a host copy.  Same explosions -> same discarded chunks, same restart points, same
+    printed lines as the synchronous loop; the chunk that ran ahead of a bad one is dropped with it."""
+    p = os.path.join(ROOT, "pinns-tf2.0_amd", "utils")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import neuralnetwork
+    from logger import Logger
+    out = {}
+    for name, cls in (("sync", _StatefulEngine), ("pipelined", _StatefulTicketEngine)):
+        monkeypatch.setattr(neuralnetwork, "Engine", cls)
+        hp = {"layers": [2, 1], "tf_epochs": 0, "tf_lr": 0.03, "tf_b1": 0.9, "tf_eps": None, "nt_epochs": 60, "nt_lr": 0.8,
+              "nt_ncorr": 50, "log_frequency": 10, "dtype": "f32"}
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            nn = neuralnetwork.NeuralNetwork(hp, Logger(hp), [1.0, 1.0], [-1.0, 0.0])
+            nn._engine.calls.clear()
+            nn._engine.pos = 0                        # (the constructor handed the engine glorot weights: start the model at 0)
+            nn.nt_optimization(np.zeros((4, 2)), np.zeros((4, 1)))
+        strip = re.compile(r"elapsed = \S+ \(\+\S+\)")
+        out[name] = (nn.nt_restarts, [strip.sub("", l) for l in buf.getvalue().splitlines() if l.startswith("nt_epoch")],
+                     nn._engine.pos, nn._engine.calls)
+    assert out["sync"][0] == out["pipelined"][0] == [(13, 10, 1.0), (27, 20, 1.0)]
+    assert out["sync"][1] == out["pipelined"][1] and [l.split()[2] for l in out["sync"][1]] == ["10", "20", "30", "40", "50"]
+    assert out["sync"][2] == out["pipelined"][2] == 60                        # both end at the same iterate
+    calls = out["pipelined"][3]
+    assert not any(c[0] in ("get", "set", "run") for c in calls)              # nothing crosses the bus, nothing synchronises
+    assert [c for c in calls if c[0] == "restore"] == [("restore", 1, 10), ("restore", 2, 20)] or \
+        [c[2] for c in calls if c[0] == "restore"] == [10, 20]
+    assert not out["pipelined"][3][-1][0] == "enq" and not nn._engine.pending   # nothing left in flight
+    assert [c for c in out["sync"][3] if c[0] == "set"] == [("set", 10), ("set", 20)]
+
+
 # ---- the L-BFGS restart guard of NeuralNetwork.nt_optimization (hp["nt_guard"]), scripted engine ---------------------------
 class _GuardEngine(object):
     """lbfgs_run follows a script of per-chunk loss lists; records the calls the guard makes"""
