@@ -179,3 +179,38 @@ def test_guarded_fit_one_chunk_behind_equals_the_synchronous_guard(burgers_sets,
     assert (len(out[True][2]) > 0) == (guard < 2)                   # the hair trigger fires, the default does not
     assert out[True][0] == out[False][0]
     assert np.array_equal(out[True][1], out[False][1])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_chunk_sizes_and_depths_equal_the_synchronous_loops(burgers_sets, seed):
+    """chunk sizes 1..60 (past the first ring size of 16 steps), one to four chunks in flight, Adam then L-BFGS: every loss,
+    every logged iteration and the final weights equal the synchronous calls on the same chunk sizes"""
+    rs = np.random.RandomState(seed)
+    sizes = [int(v) for v in rs.randint(1, 61, size=9)]
+    a, b = _engine(burgers_sets, N_u=64, N_f=2048), _engine(burgers_sets, N_u=64, N_f=2048)
+    want = np.concatenate([a.adam_run(n) for n in sizes])
+    got, queue = [], []
+    for n in sizes:
+        queue.append(b.adam_enqueue(n))
+        while len(queue) > int(rs.randint(0, 4)):                  # keep 0..3 chunks in flight behind this one
+            got.append(b.adam_collect(queue.pop(0)))
+    got += [b.adam_collect(t) for t in queue]
+    assert np.array_equal(np.concatenate(got), want) and np.array_equal(a.get_weights(), b.get_weights())
+    eps, total = float(np.finfo(float).eps), sum(sizes) // 2
+    a.lbfgs_begin(total, 0.8, 50, eps); b.lbfgs_begin(total, 0.8, 50, eps)
+    ia, la, done, k = [], [], 0, 0
+    while not done:
+        i, l, done = a.lbfgs_run(sizes[k % len(sizes)]); k += 1
+        ia.append(i); la.append(l)
+    ib, lb_, done, k, queue = [], [], 0, 0, []
+    while not done:
+        queue.append(b.lbfgs_enqueue(sizes[k % len(sizes)])); k += 1
+        if len(queue) > int(rs.randint(0, 3)):
+            i, l, done = b.lbfgs_collect(queue.pop(0))
+            ib.append(i); lb_.append(l)
+    for t in queue:
+        i, l, _ = b.lbfgs_collect(t)
+        ib.append(i); lb_.append(l)
+    assert np.array_equal(np.concatenate(ia), np.concatenate(ib)) and np.array_equal(np.concatenate(la), np.concatenate(lb_))
+    assert np.array_equal(a.get_weights(), b.get_weights()) and np.array_equal(a.lbfgs_x(), b.lbfgs_x())
+    a.close(); b.close()
