@@ -348,7 +348,7 @@ class NeuralNetwork(object):
         the stream while this process formats and prints the previous chunk's lines, so a log line costs the device
         nothing.  Same chunks, same kernels, same numbers as the synchronous loops.  Off (hp["async_log"] = false, or
         automatically) when a line needs more than the chunk's losses: subclasses that append text read from the device
-        (_log_custom: the identification scripts' lambdas) or print per evaluation (_adam_chunk: Schrodinger), periodic
+        (_log_custom: the discrete-time identification script's lambdas) or print per evaluation (_adam_chunk: Schrodinger), periodic
         resampling.  The restart guard goes along: its way back is a device-side snapshot behind every chunk."""
         cls = type(self)
         return (self._async_log and cls._log_custom is NeuralNetwork._log_custom
