@@ -140,6 +140,7 @@ int pinn_lbfgs_run(pinn_ctx* c, int n_iters, int* iters, double* losses, int* n_
  * pinn_lbfgs_collect: iters / losses hold `cap` entries (enough: the iterations enqueued since the last collect + 1).
  * An L-BFGS chunk enqueued after the run has ended (done != 0 seen one chunk late) changes nothing on the device. */
 int pinn_adam_enqueue(pinn_ctx* c, int n_steps, int* ticket);
+int pinn_adam_enqueue_terms(pinn_ctx* c, int n_steps, int* ticket);   /* as pinn_adam_run_terms: collect returns 3 n values */
 int pinn_adam_collect(pinn_ctx* c, int ticket, double* losses);
 int pinn_lbfgs_enqueue(pinn_ctx* c, int n_iters, int* ticket);
 int pinn_lbfgs_collect(pinn_ctx* c, int ticket, int cap, int* iters, double* losses, int* n_logged, int* done);

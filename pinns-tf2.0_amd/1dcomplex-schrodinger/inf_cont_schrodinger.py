@@ -73,6 +73,16 @@ class SchrodingerInformedNN(NeuralNetwork):
                 print(f"mse_0 {data}    mse_b {bnd}    mse_f    {res}")
         return terms.sum(axis=1)
 
+    def _adam_enqueue(self, n):                      # the same chunk one chunk behind the GPU (utils/neuralnetwork.py _pipelined)
+        return self._engine.adam_enqueue(n, terms=True)
+
+    def _adam_collect(self, ticket):
+        terms = self._engine.adam_collect(ticket)
+        if not self._quiet_parts and self.is_root:
+            for res, data, bnd in terms:
+                print(f"mse_0 {data}    mse_b {bnd}    mse_f    {res}")
+        return terms.sum(axis=1)
+
     def predict(self, X_star):
         h_pred = self.model(X_star)
         return h_pred[:, 0:1], h_pred[:, 1:2]

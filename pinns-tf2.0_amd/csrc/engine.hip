@@ -1552,6 +1552,15 @@ int pinn_adam_enqueue(pinn_ctx* c, int n_steps, int* ticket) {
   return adam_issue(c, n_steps, true, ticket);
 }
 
+// the chunk of pinn_adam_run_terms: pinn_adam_collect hands back 3 n values, (residual, data, boundary) before every update
+int pinn_adam_enqueue_terms(pinn_ctx* c, int n_steps, int* ticket) {
+  REQUIRE(c && ticket && n_steps >= 1, "bad arguments");
+  c->adam_want_terms = true;
+  const int rc = adam_issue(c, n_steps, true, ticket);
+  c->adam_want_terms = false;
+  return rc;
+}
+
 int pinn_adam_collect(pinn_ctx* c, int ticket, double* losses) { return adam_collect(c, ticket, losses); }
 
 int pinn_adam_run_terms(pinn_ctx* c, int n_steps, double* terms3) {

@@ -177,6 +177,7 @@ _SIGNATURES = {
     "pinn_lbfgs_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p, _c_double_p,
                                       _c_int_p, _c_int_p]),
     "pinn_adam_enqueue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
+    "pinn_adam_enqueue_terms": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
     "pinn_adam_collect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_double_p]),
     "pinn_lbfgs_enqueue": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, _c_int_p]),
     "pinn_lbfgs_collect": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, _c_int_p, _c_double_p,
@@ -536,17 +537,20 @@ class Engine(object):
     # -- the same loops with the host one chunk behind the GPU (include/pinn_hip.h: pinn_*_enqueue / _collect) --------
     MAX_IN_FLIGHT = 4
 
-    def adam_enqueue(self, n_steps):
-        """n_steps Adam iterations into the stream -> ticket (returns at once); adam_collect(ticket) -> their losses"""
+    def adam_enqueue(self, n_steps, terms=False):
+        """n_steps Adam iterations into the stream -> ticket (returns at once); adam_collect(ticket) -> their losses
+        ([n] sums, or with terms=True the [n, 3] parts (residual, data, boundary) of adam_run_terms)"""
         t = ctypes.c_int(0)
-        self._check(self._lib.pinn_adam_enqueue(self._h, int(n_steps), ctypes.byref(t)))
+        fn = self._lib.pinn_adam_enqueue_terms if terms else self._lib.pinn_adam_enqueue
+        self._check(fn(self._h, int(n_steps), ctypes.byref(t)))
         self._tickets = getattr(self, "_tickets", {})
-        self._tickets[t.value] = int(n_steps)
+        self._tickets[t.value] = -int(n_steps) if terms else int(n_steps)      # (negative: a terms chunk)
         return t.value
 
     def adam_collect(self, ticket):
         n = self._tickets[ticket]
-        losses = np.empty(max(n, 1), dtype=np.float64)
+        terms, n = n < 0, abs(n)
+        losses = np.empty((max(n, 1), 3) if terms else max(n, 1), dtype=np.float64)
         self._check(self._lib.pinn_adam_collect(self._h, int(ticket), _dp(losses)))
         del self._tickets[ticket]
         return losses[:n]
@@ -568,7 +572,7 @@ class Engine(object):
         self._check(self._lib.pinn_lbfgs_collect(self._h, int(ticket), cap, iters.ctypes.data_as(_c_int_p), _dp(losses),
                                                  ctypes.byref(n_logged), ctypes.byref(done)))
         del self._tickets[ticket]
-        self._lb_uncollected = sum(self._tickets.values())
+        self._lb_uncollected = sum(abs(v) for v in self._tickets.values())
         k = n_logged.value
         return iters[:k].copy(), losses[:k].copy(), done.value
 

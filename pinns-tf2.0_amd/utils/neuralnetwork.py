@@ -348,11 +348,12 @@ class NeuralNetwork(object):
         the stream while this process formats and prints the previous chunk's lines, so a log line costs the device
         nothing.  Same chunks, same kernels, same numbers as the synchronous loops.  Off (hp["async_log"] = false, or
         automatically) when a line needs more than the chunk's losses: subclasses that append text read from the device
-        (_log_custom: the discrete-time identification script's lambdas) or print per evaluation (_adam_chunk: Schrodinger), periodic
-        resampling.  The restart guard goes along: its way back is a device-side snapshot behind every chunk."""
+        (_log_custom: the discrete-time identification script's lambdas) or print per evaluation without
+        the enqueue / collect pair (_adam_chunk alone), periodic resampling.  The restart guard goes along: its way back is a device-side snapshot behind every chunk."""
         cls = type(self)
-        return (self._async_log and cls._log_custom is NeuralNetwork._log_custom
-                and cls._adam_chunk is NeuralNetwork._adam_chunk and hasattr(self._engine, "adam_enqueue"))
+        chunk_ok = cls._adam_chunk is NeuralNetwork._adam_chunk or cls._adam_collect is not NeuralNetwork._adam_collect
+        return (self._async_log and cls._log_custom is NeuralNetwork._log_custom and chunk_ok
+                and hasattr(self._engine, "adam_enqueue"))
 
     def _log_boundaries(self, total, freq):
         """chunk ends: every chunk runs up to and including the next epoch that is logged (0, freq, 2 freq, ...)"""
@@ -366,17 +367,24 @@ class NeuralNetwork(object):
         eng, start, queue = self._engine, 0, []
         for stop in self._log_boundaries(self.tf_epochs, freq) + [None]:
             if stop is not None:
-                queue.append((start, eng.adam_enqueue(stop - start)))
+                queue.append((start, self._adam_enqueue(stop - start)))
                 start = stop
             while queue and (stop is None or len(queue) > 1):       # keep ONE chunk ahead of the one being logged
                 first, ticket = queue.pop(0)
-                for k, loss_value in enumerate(eng.adam_collect(ticket)):
+                for k, loss_value in enumerate(self._adam_collect(ticket)):
                     self.logger.log_train_epoch(first + k, loss_value, "")
 
     def _adam_chunk(self, n):
         """n device-resident Adam steps; the loss before each update.  Subclasses that print per-evaluation
-        diagnostics (the Schrodinger loss parts) override this."""
+        diagnostics (the Schrodinger loss parts) override this -- and _adam_enqueue / _adam_collect beside it if they want
+        their lines one chunk behind the GPU as well."""
         return self._engine.adam_run(n)
+
+    def _adam_enqueue(self, n):
+        return self._engine.adam_enqueue(n)
+
+    def _adam_collect(self, ticket):
+        return self._engine.adam_collect(ticket)
 
     def tf_optimization_step(self, X_u, u):
         self._bind(X_u, u)

@@ -214,3 +214,36 @@ def test_random_chunk_sizes_and_depths_equal_the_synchronous_loops(burgers_sets,
     assert np.array_equal(np.concatenate(ia), np.concatenate(ib)) and np.array_equal(np.concatenate(la), np.concatenate(lb_))
     assert np.array_equal(a.get_weights(), b.get_weights()) and np.array_equal(a.lbfgs_x(), b.lbfgs_x())
     a.close(); b.close()
+
+
+def test_schrodinger_per_evaluation_lines_one_chunk_behind(schrodinger_sets, monkeypatch):
+    """the Schrodinger class prints mse_0 / mse_b / mse_f on EVERY evaluation (1dcomplex-schrodinger/inf_cont_schrodinger.py:128):
+    its chunks travel as pinn_adam_enqueue_terms; stdout (progress lines and the per-evaluation lines, in order) and the final
+    weights equal the synchronous run's"""
+    import os
+    import runpy
+    import sys
+    import neuralnetwork
+    from conftest import PKG
+    from logger import Logger
+    monkeypatch.setattr(sys, "argv", ["inf_cont_schrodinger.py"])
+    g = runpy.run_path(os.path.join(PKG, "1dcomplex-schrodinger", "inf_cont_schrodinger.py"), run_name="schro")
+    r = schrodinger_sets(50, 50, 20000)
+    X_f, ub, lb, tb, x0, u0, v0 = r[11], r[12], r[13], r[14], r[15], r[16], r[17]
+    out = {}
+    for mode in (True, False):
+        hp = dict(g["hp"], tf_epochs=23, log_frequency=5, async_log=mode)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            neuralnetwork.set_seed(1234)
+            pinn = g["SchrodingerInformedNN"](hp, Logger(hp), X_f, tb, ub, lb)
+            assert pinn._pipelined() is mode
+            pinn.logger.set_error_fn(lambda: 0.5)
+            pinn.fit(x0, np.concatenate([u0, v0], 1))
+        strip = re.compile(r"elapsed = \S+ \(\+\S+\)")
+        lines = [strip.sub("", l) for l in buf.getvalue().splitlines() if l.startswith(("tf_epoch", "mse_0"))]
+        out[mode] = (lines, pinn.get_weights())
+        pinn._engine.close()
+    assert out[True][0] == out[False][0]
+    assert sum(l.startswith("mse_0") for l in out[True][0]) == 23 and sum(l.startswith("tf_epoch") for l in out[True][0]) == 5
+    assert np.array_equal(out[True][1], out[False][1])
