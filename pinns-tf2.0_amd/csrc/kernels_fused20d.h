@@ -59,6 +59,9 @@
                                  //  2  as 1, barrier + reads in front of the adjoint arithmetic (pure VALU) as well
                                  // same-box: 36.9 / 35.6 / 35.0 us with the ds_bpermute moves (profiles/r06_ab_onetile_v3, _v4)
 #endif
+#ifndef PINN_GACC_ATOMIC
+#define PINN_GACC_ATOMIC 1       // tile loop: gradient accumulators updated by ds_add_f64 from the lanes of block 0 (0: read-add-write)
+#endif
 #ifndef PINN_PA_LOOP
 #define PINN_PA_LOOP 1           // the pinned GEMV loops in the tile-loop variants too: N_f = 10^6 1868 -> 1851 us, same box
                                  // (profiles/r06_ab_loopvariants.txt; with the ds_bpermute rotations of rounds 2-5 this was a loss)
@@ -275,17 +278,65 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     int lane_o = tid & 63;
     if (!ONE_TILE && PINN_OPAQUE_TILE_D) asm volatile("" : "+v"(lane_o));
     PINN_LANE_INDICES(lane_o);
-    auto grad_fetch = [&](const int blk) { return ONE_TILE ? 0.0 : gacc[blk * 16 + ge]; };
+    auto grad_fetch = [&](const int blk) { return (ONE_TILE || PINN_GACC_ATOMIC) ? 0.0 : gacc[blk * 16 + ge]; };
     // One tile per workgroup: nothing is accumulated, so the four blocks are not folded in registers (2 x 2 DPP moves + 2
     // adds per block, 1 300 instructions per tile): every lane parks its own partial in the phase's staging buffer
     // (entry-major: the four blocks of an entry adjacent), and phase_sum adds blocks and waves with the whole workgroup.
     int phase_first = 0;
     double* stage_w = gacc_all + wave * FUSED20D_STAGE_WAVE;
+    // Tile loop (PINN_GACC_ATOMIC): the folded total sits in all four lanes of an entry; the lanes of block 0 add it into the
+    // wave's accumulator with ONE ds_add_f64 (16 distinct addresses, one adder per address and tile: no conflict,
+    // bit-reproducible) instead of a ds_read of the old value long before, a v_add_f64 and a ds_write.  A group's stores
+    // share one hand-set execution-mask region: as `if (block 0) atomic` every store became its own basic block (two scalar
+    // instructions each, and the stash reads the compiler shares between a layer's rotated inputs and the next layer's
+    // adjoints were issued twice: 9 233 -> 9 766 instructions).  LDS operations the compiler does not see only make its own
+    // lgkmcnt waits conservative (the queue is in order).  (The UNFOLDED form -- four lanes per address -- was 14 % slower
+    // in round 2; this one follows the fold.)
+    double pend_D[6] = {0, 0, 0, 0, 0, 0};
+    int pend_off[6] = {0, 0, 0, 0, 0, 0}, pend_n = 0;
+    auto gacc_flush = [&]() {
+#if PINN_GACC_ATOMIC
+      if constexpr (!ONE_TILE) {
+        const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(gacc + ge);
+        unsigned long long saved;
+        if (pend_n == 6)
+          asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mk]\n\t"
+                       "ds_add_f64 %[a], %[d0] offset:%[o0]\n\tds_add_f64 %[a], %[d1] offset:%[o1]\n\t"
+                       "ds_add_f64 %[a], %[d2] offset:%[o2]\n\tds_add_f64 %[a], %[d3] offset:%[o3]\n\t"
+                       "ds_add_f64 %[a], %[d4] offset:%[o4]\n\tds_add_f64 %[a], %[d5] offset:%[o5]\n\t"
+                       "s_mov_b64 exec, %[sv]"
+                       : [sv] "=&s"(saved)
+                       : [a] "v"(addr), [mk] "s"(0x000f000f000f000full), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
+                         [d2] "v"(pend_D[2]), [d3] "v"(pend_D[3]), [d4] "v"(pend_D[4]), [d5] "v"(pend_D[5]),
+                         [o0] "i"(pend_off[0]), [o1] "i"(pend_off[1]), [o2] "i"(pend_off[2]), [o3] "i"(pend_off[3]),
+                         [o4] "i"(pend_off[4]), [o5] "i"(pend_off[5])
+                       : "memory");
+        else
+          asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mk]\n\t"
+                       "ds_add_f64 %[a], %[d0] offset:%[o0]\n\tds_add_f64 %[a], %[d1] offset:%[o1]\n\t"
+                       "ds_add_f64 %[a], %[d2] offset:%[o2]\n\tds_add_f64 %[a], %[d3] offset:%[o3]\n\t"
+                       "ds_add_f64 %[a], %[d4] offset:%[o4]\n\t"
+                       "s_mov_b64 exec, %[sv]"
+                       : [sv] "=&s"(saved)
+                       : [a] "v"(addr), [mk] "s"(0x000f000f000f000full), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
+                         [d2] "v"(pend_D[2]), [d3] "v"(pend_D[3]), [d4] "v"(pend_D[4]),
+                         [o0] "i"(pend_off[0]), [o1] "i"(pend_off[1]), [o2] "i"(pend_off[2]), [o3] "i"(pend_off[3]),
+                         [o4] "i"(pend_off[4])
+                       : "memory");
+      }
+#endif
+      pend_n = 0;
+    };
     auto grad_store = [&](double D, const double old, const int blk) {
       if (ONE_TILE) { stage_w[(blk - phase_first) * 64 + sput] = D; return; }
       D += dpp_mov<DPP_ROW_ROR8>(D);
       D += dpp_mov<DPP_ROW_ROR4>(D);
+#if PINN_GACC_ATOMIC
+      pend_D[pend_n] = D; pend_off[pend_n] = blk * 128; ++pend_n;      // added by gacc_flush below, one execution-mask region per group
+      (void)old;
+#else
       gacc[blk * 16 + ge] = old + D;
+#endif
     };
     // entries of a hidden layer's 30 blocks, relative to the layer's first weight: the same for every layer, derived once.
     // Thread t owns entries t and t + 256 of a phase.
@@ -468,6 +519,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         stage_w = gacc_all + wave * FUSED20D_STAGE_WAVE;
 #pragma unroll
         for (int m = 0; m < 6; ++m) grad_store(D[m], old[m], BLK_H + m);
+        gacc_flush();
       }
 #pragma unroll
       for (int n = 0; n < 5; ++n) {
@@ -597,6 +649,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         }
 #pragma unroll
         for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + m * 5 + n);
+        gacc_flush();
 #pragma unroll
         for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
         STAMP2(d == 4, 23 + m);
@@ -610,6 +663,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
         for (int n = 0; n < 5; ++n) D[n] = mfma444(onesA, zbT[0][n], 0.0);
 #pragma unroll
         for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], base + 25 + n);
+        gacc_flush();
       }
       STAMP(2 * H + 1 - d);
     }
@@ -643,6 +697,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
       stage_w = gacc_all + (H & 1) * FUSED20D_STAGE_BUF + wave * FUSED20D_STAGE_WAVE;
 #pragma unroll
       for (int n = 0; n < 5; ++n) grad_store(D[n], old[n], n);
+      gacc_flush();
       if constexpr (ONE_TILE) {
         phase_issue(5 * 16, H & 1);
         phase_finish(5 * 16, [&](const int e, int) {
