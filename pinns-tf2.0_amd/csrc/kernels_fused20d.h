@@ -59,6 +59,13 @@
                                  //  2  as 1, barrier + reads in front of the adjoint arithmetic (pure VALU) as well
                                  // same-box: 36.9 / 35.6 / 35.0 us with the ds_bpermute moves (profiles/r06_ab_onetile_v3, _v4)
 #endif
+#ifndef PINN_FOLD_STAGES
+#define PINN_FOLD_STAGES 1       // tile loop: DPP fold stages in front of the ds_add_f64.  1 = the blocks are folded once (b with
+                                 // b ^ 2) and the lanes of blocks 0 and 1 add into the accumulator -- two lanes per address in one
+                                 // LDS instruction (resolved in lane order: run-to-run bit equality is asserted by the tile-loop
+                                 // tests).  Same box, N_f = 10^6: 2 stages 1778 us, 1 stage 1738 us, 0 stages (four lanes per
+                                 // address) 2110 us (profiles/r06_ab_foldstages.txt)
+#endif
 #ifndef PINN_GACC_ATOMIC
 #define PINN_GACC_ATOMIC 1       // tile loop: gradient accumulators updated by ds_add_f64 from the lanes of block 0 (0: read-add-write)
 #endif
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
                        "ds_add_f64 %[a], %[d4] offset:%[o4]\n\tds_add_f64 %[a], %[d5] offset:%[o5]\n\t"
                        "s_mov_b64 exec, %[sv]"
                        : [sv] "=&s"(saved)
-                       : [a] "v"(addr), [mk] "s"(0x000f000f000f000full), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
+                       : [a] "v"(addr), [mk] "s"(PINN_FOLD_STAGES == 2 ? 0x000f000f000f000full : PINN_FOLD_STAGES == 1 ? 0x00ff00ff00ff00ffull : 0xffffffffffffffffull), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
                          [d2] "v"(pend_D[2]), [d3] "v"(pend_D[3]), [d4] "v"(pend_D[4]), [d5] "v"(pend_D[5]),
                          [o0] "i"(pend_off[0]), [o1] "i"(pend_off[1]), [o2] "i"(pend_off[2]), [o3] "i"(pend_off[3]),
                          [o4] "i"(pend_off[4]), [o5] "i"(pend_off[5])
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
                        "ds_add_f64 %[a], %[d4] offset:%[o4]\n\t"
                        "s_mov_b64 exec, %[sv]"
                        : [sv] "=&s"(saved)
-                       : [a] "v"(addr), [mk] "s"(0x000f000f000f000full), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
+                       : [a] "v"(addr), [mk] "s"(PINN_FOLD_STAGES == 2 ? 0x000f000f000f000full : PINN_FOLD_STAGES == 1 ? 0x00ff00ff00ff00ffull : 0xffffffffffffffffull), [d0] "v"(pend_D[0]), [d1] "v"(pend_D[1]),
                          [d2] "v"(pend_D[2]), [d3] "v"(pend_D[3]), [d4] "v"(pend_D[4]),
                          [o0] "i"(pend_off[0]), [o1] "i"(pend_off[1]), [o2] "i"(pend_off[2]), [o3] "i"(pend_off[3]),
                          [o4] "i"(pend_off[4])
@@ -329,8 +336,12 @@ __global__ __launch_bounds__(256) void k_fused20d(const double* __restrict__ th,
     };
     auto grad_store = [&](double D, const double old, const int blk) {
       if (ONE_TILE) { stage_w[(blk - phase_first) * 64 + sput] = D; return; }
+#if PINN_GACC_ATOMIC && PINN_FOLD_STAGES < 2
+      if (PINN_FOLD_STAGES == 1) D += dpp_mov<DPP_ROW_ROR8>(D);       // the LDS adder does the rest of the fold
+#else
       D += dpp_mov<DPP_ROW_ROR8>(D);
       D += dpp_mov<DPP_ROW_ROR4>(D);
+#endif
 #if PINN_GACC_ATOMIC
       pend_D[pend_n] = D; pend_off[pend_n] = blk * 128; ++pend_n;      // added by gacc_flush below, one execution-mask region per group
       (void)old;
